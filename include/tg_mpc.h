@@ -1,0 +1,175 @@
+/*
+ * tg_mpc.h -- C ABI of the MI355X batched MPC engine (libtg_mpc.so).
+ *
+ * The reference (mzahana/trajectory_generation) has no FFI layer: its hot path sits
+ * behind the public methods of two C++ classes,
+ *     class MPC         include/trajectory_generation/mpc_6dof.hpp:282-404
+ *     class MPC12STATE  include/trajectory_generation/mpc_12state.hpp:492-683
+ * which build a horizon QP with Eigen and hand it to OSQP through osqp-eigen.  The
+ * entry points below are what a binding of those two classes to this engine needs;
+ * each one names the reference method(s) it replaces.  Plain C types only; every
+ * buffer passed in is owned by the caller and is never freed by the library.
+ *
+ * Conventions
+ *   - return value: 0 = success, negative = TG_E_* error (tg_last_error() has text)
+ *   - "device" pointers are HIP device pointers on the handle's GPU
+ *   - batched device arrays are structure-of-arrays, instance-minor:
+ *         element (row r, instance b) lives at  ptr[r * ld + b],  ld >= B
+ *     so that one wavefront reads 64 consecutive instances of one row
+ *   - host-side batched arrays are instance-major (one reference-style vector per
+ *     instance, back to back), exactly the vectors the reference's methods take
+ *   - status per instance: 1 solved, -2 max_iter reached, -3 primal infeasible
+ *     detected (OSQP status numbering, what osqp-eigen's solve() turns into the bool)
+ */
+#ifndef TG_MPC_H
+#define TG_MPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_INFTY 1e30 /* OsqpEigen::INFTY, mpc_6dof.cpp:306-308 */
+
+enum { TG_OK = 0, TG_E_ARG = -1, TG_E_HIP = -2, TG_E_STATE = -3, TG_E_NUMERIC = -4 };
+enum { TG_SOLVED = 1, TG_MAX_ITER = -2, TG_PRIMAL_INFEASIBLE = -3, TG_UNSOLVED = -10 };
+enum { TG_FAM_6DOF = 0, TG_FAM_XY = 1, TG_FAM_Z = 2, TG_FAM_YAW = 3 };
+enum { TG_MAT_P = 0, TG_MAT_A = 1, TG_MAT_AD = 2, TG_MAT_BD = 3, TG_MAT_Q = 4, TG_MAT_R = 5,
+       TG_MAT_KINV = 6, TG_VEC_L = 7, TG_VEC_U = 8, TG_VEC_RHO = 9 };
+
+/* MPC setters: setDt, setMPCWindow, setStateWeight, setInputWeight, setSmoothInputWeight,
+ * enableControlSmoothing, setMinimumAltitude, setMaxVel, setMaxAccel
+ * (mpc_6dof.cpp:60-227).  Frozen by tg_mpc6_create, as by MPC::initMPCProblem. */
+typedef struct {
+    int    N;
+    double dt;
+    double state_weight, input_weight, smooth_input_weight;
+    int    enable_control_smoothing;
+    double min_altitude;
+    double max_vel[3], max_accel[3];
+} tg_mpc6_params;
+
+/* MPC12STATE setters (mpc_12state.cpp:1571-1932); triples are per stage */
+typedef struct {
+    int    N;
+    double dt;
+    int    enable_control_smoothing;
+    double xy_state_weight, z_state_weight, yaw_state_weight;
+    double xy_input_weight, z_input_weight, yaw_input_weight;
+    double xy_smooth_input_weight, z_smooth_input_weight, yaw_smooth_input_weight;
+    double xy_max_vel, z_max_vel, yaw_max_vel;
+    double xy_max_accel, z_max_accel, yaw_max_accel;
+    double xy_max_jerk, z_max_jerk, yaw_max_jerk;
+} tg_mpc12_params;
+
+/* Solver options.  The reference leaves every OSQP setting at its default except
+ * warm start (mpc_6dof.cpp:527-528, mpc_12state.cpp:1024-1065); the engine runs the
+ * same ADMM with OSQP's scaling and rho adaptation switched off and a fixed rho.
+ * rho <= 0 selects the built-in per-family choice. */
+typedef struct {
+    double rho;               /* <=0: automatic */
+    double sigma;             /* 1e-6 */
+    double alpha;             /* 1.6  */
+    double eps_abs, eps_rel;  /* 1e-3 */
+    int    max_iter;          /* 4000 */
+    int    check_termination; /* 25   */
+} tg_solver_opts;
+
+void tg_default_opts(tg_solver_opts *o);
+const char *tg_last_error(void);
+int tg_device_count(void);
+
+/* ------------------------------------------------------------------ 6-DOF (class MPC) */
+typedef struct tg_mpc6 tg_mpc6;
+
+/* MPC::MPC + MPC::initMPCProblem (mpc_6dof.cpp:552-580): builds P, A, bounds, the
+ * shared reduced-KKT inverse, and uploads them to GPU `device`. */
+int tg_mpc6_create(const tg_mpc6_params *p, const tg_solver_opts *o, int device, tg_mpc6 **out);
+void tg_mpc6_destroy(tg_mpc6 *h);
+
+/* B independent MPC::mpcLoop calls (mpc_6dof.cpp:616-649): updateQP + solve +
+ * extractSolution.  Device SoA arrays:
+ *   x0  [6][ld]          setCurrentState   mpc_6dof.cpp:175
+ *   ref [6(N+1)][ld]     setReferenceTraj  mpc_6dof.cpp:794
+ *   X   [6(N+1)][ld]     getOptimalStateTraj   :805
+ *   U   [3N][ld]         getOptimalControlTraj :811
+ *   status[B], iters[B]  (may be NULL)
+ * warm != 0 continues from the iterates the handle keeps for slots [0,B) (the
+ * reference's setWarmStart(true), mpc_6dof.cpp:528) and stores the new ones; the
+ * first warm call of a handle starts cold.  stream: hipStream_t or NULL. */
+int tg_mpc6_solve_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm,
+                        void *stream);
+
+/* same on host vectors, instance-major (x0[B][6], ref[B][6(N+1)], X[B][6(N+1)], U[B][3N]) */
+int tg_mpc6_solve_host(tg_mpc6 *h, int B, const double *x0, const double *ref, double *X,
+                       double *U, int *status, int *iters, int warm);
+
+/* castMPCToQPGradient / castMPCToQPConstraintBounds for a batch (mpc_6dof.cpp:371,450):
+ * the full per-instance q [n][ld], l [m][ld], u [m][ld] in the reference's ordering. */
+int tg_mpc6_assemble_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                           double *d_q, double *d_l, double *d_u, void *stream);
+
+/* drop the stored warm-start iterates */
+int tg_mpc6_reset_warm(tg_mpc6 *h);
+/* getters of the reference (getHessianMatrix, getContraintsMatrix, getTransitionMatrix,
+ * getInputMatrix, getQ, getR, getLowerBounds, getUpperBounds  mpc_6dof.cpp:841-885);
+ * row-major, sizes from tg_mpc6_dims; bounds are the init-time ones (x0 = 0) */
+int tg_mpc6_dims(const tg_mpc6 *h, int *n, int *m);
+int tg_mpc6_get(const tg_mpc6 *h, int which, double *out);
+double tg_mpc6_rho(const tg_mpc6 *h);
+
+/* ------------------------------------------------------------------ 12-state (class MPC12STATE) */
+typedef struct tg_mpc12 tg_mpc12;
+
+/* MPC12STATE::initMPCProblem (mpc_12state.cpp:1282-1350); opts apply to all three
+ * stages, rho_xyz (may be NULL) overrides the per-stage automatic rho {xy, z, yaw} */
+int tg_mpc12_create(const tg_mpc12_params *p, const tg_solver_opts *o, const double *rho_xyz,
+                    int device, tg_mpc12 **out);
+void tg_mpc12_destroy(tg_mpc12 *h);
+
+/* B independent MPC12STATE::mpcLoop calls (mpc_12state.cpp:1374-1453):
+ * Z solve -> computeXYBounds -> XY solve -> computeYawRefTrajectory -> Yaw solve -> merge.
+ *   x0  [12][ld], ref [12(N+1)][ld], X [12(N+1)][ld], U [4N][ld]
+ *   status[3][ld], iters[3][ld]   rows = {z, xy, yaw} stage   (may be NULL)
+ * warm: as above (a deviation from the reference, which cold-starts all three
+ * solvers, mpc_12state.cpp:1025,1045,1065; used by closed-loop roll-outs). */
+int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                         double *d_X, double *d_U, int *d_status, int *d_iters, int warm,
+                         void *stream);
+int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref, double *X,
+                        double *U, int *status, int *iters, int warm);
+
+/* single stages with the upstream solution injected, for stage-by-stage checks:
+ * stage = TG_FAM_Z / TG_FAM_XY / TG_FAM_YAW.  For XY, X must already hold the z rows
+ * (6..8 of every step); for YAW, the xy rows (0..5). */
+int tg_mpc12_solve_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0,
+                         const double *d_ref, double *d_X, double *d_U, int *d_status,
+                         int *d_iters, void *stream);
+/* intermediate products of the last tg_mpc12_solve_* call on this handle (device, SoA with
+ * the ld of that call): xy_max [6N], mixed_max [6N] (computeXYBounds :724), yaw_ref [N+1]
+ * (computeYawRefTrajectory :525) */
+int tg_mpc12_intermediates(tg_mpc12 *h, const double **d_xy_max, const double **d_mixed_max,
+                           const double **d_yaw_ref, int *ld);
+int tg_mpc12_assemble_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0,
+                            const double *d_ref, const double *d_X, double *d_q, double *d_l,
+                            double *d_u, void *stream);
+int tg_mpc12_reset_warm(tg_mpc12 *h);
+int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m);
+int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out);
+double tg_mpc12_rho(const tg_mpc12 *h, int stage);
+
+/* device -> host copy of `bytes` bytes on the current device (for callers without a HIP
+ * runtime of their own, e.g. a ctypes binding reading tg_mpc12_intermediates) */
+int tg_copy_to_host(void *dst, const void *d_src, unsigned long long bytes);
+
+/* ------------------------------------------------------------------ kernel timing hook */
+/* Average duration (ms) and launch count of the ADMM kernel over the launches made since
+ * the last call with reset != 0; measured with HIP events on the launch stream when
+ * timing is enabled.  Used by the benchmark's roofline line. */
+void tg_timing_enable(int on);
+int tg_timing_read(double *admm_ms_total, int *admm_launches, double *iters_total, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

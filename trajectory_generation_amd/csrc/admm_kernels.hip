@@ -1,0 +1,637 @@
+// gfx950 kernels of the batched MPC engine.
+//
+//   admm_kernel      one workgroup = 16 instances of one QP stage, resident on chip for
+//                    all ADMM iterations; the shared reduced-KKT inverse is applied with
+//                    v_mfma_f64_16x16x4_f64 (instances are the 16 MFMA columns)
+//   assemble_kernel  per-instance q, l, u of the reference's QP (castMPCToQPGradient /
+//                    castMPCToQPConstraintBounds, mpc_6dof.cpp:371,450 and the 12-state twins)
+//   xy_bounds_kernel MPC12STATE::computeXYBounds        (mpc_12state.cpp:724-791)
+//   yaw_ref_kernel   MPC12STATE::computeYawRefTrajectory (mpc_12state.cpp:525-552)
+//
+// ADMM iteration (OSQP Algorithm 1 with scaling and rho adaptation off), per instance:
+//   xt = Kinv (sigma x - q + A'(rho z - y));  zt = A xt
+//   x  = alpha xt + (1-alpha) x
+//   zr = alpha zt + (1-alpha) z;  z+ = clamp(zr + y/rho, l, u);  y+ = y + rho (zr - z+)
+// The kernel keeps yr = y/rho.  The rows of A (castMPCToQPConstraintMatrix,
+// mpc_6dof.cpp:409, mpc_12state.cpp:571/641/683) are never stored: a thread owns whole
+// "cells" (one horizon step of one axis: D integrator states + the input) and applies the
+// dynamics / box / mixed rows of its cells as fixed stencils on neighbouring cells.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_types.h"
+
+namespace tg {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi)
+{
+    return fmin(fmax(v, lo), hi);
+}
+
+// max over the four lanes that share an instance inside one wave (lane bits 4 and 5)
+__device__ __forceinline__ double wave_gmax(double v)
+{
+    v = fmax(v, __shfl_xor(v, 16));
+    v = fmax(v, __shfl_xor(v, 32));
+    return v;
+}
+
+__device__ __forceinline__ void lds_max(unsigned long long *p, double v)
+{
+    atomicMax(p, (unsigned long long)__double_as_longlong(v));
+}
+
+// Coefficient of state l of step i in dynamics row k of step i+1 (l >= k): the upper
+// triangular Toeplitz block [1 dt dt^2/2; 0 1 dt; 0 0 1] (D = 3) or [1 dt; 0 1] (D = 2).
+template <int D> __device__ __forceinline__ double chain_coef(int k, int l, double dt, double c2)
+{
+    const int d = l - k;
+    return d == 0 ? 1.0 : (d == 1 ? dt : c2);
+}
+
+template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR>
+__global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const BatchArgs a)
+{
+    constexpr int S = D + 1;
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    const int t = tid & 15, g = tid >> 4;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int inst = blockIdx.x * kTileDev + t;
+    const bool valid = inst < a.B;
+    const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
+    const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
+
+    // LDS carve-up (all [rows][16 instances] of doubles)
+    double *v0 = lds;                                                       // rhs
+    double *vx = P.separate_xt ? lds + (size_t)n_int * 16 : lds;            // xt (and x during checks)
+    double *weq = lds + (size_t)(P.separate_xt ? 2 : 1) * n_int * 16;       // w of dynamics rows [ncell*D]
+    double *wmx = weq + (size_t)ncell * D * 16;                             // w of mixed rows [N1*6]
+    double *ctab = wmx + (MIXED ? (size_t)N1 * 6 * 16 : 0);                 // [NAX][S][3] rho, lb, ub
+    unsigned long long *red = (unsigned long long *)(ctab + NAX * S * 3);   // [7][16]
+
+    const double sigma = P.sigma, alpha = P.alpha, oma = 1.0 - P.alpha;
+    const double dt = P.dt, c2 = P.c2, rho_eq = P.rho_eq;
+    constexpr double s3 = 0.86602540378443864676, s2 = 0.70710678118654752440; // sqrt(3)/2, sqrt(2)/2
+
+    if (tid < NAX * S) {
+        const int ax = tid / S, k = tid % S;
+        ctab[tid * 3 + 0] = P.rho_box[ax][k];
+        ctab[tid * 3 + 1] = P.lb[ax][k];
+        ctab[tid * 3 + 2] = P.ub[ax][k];
+    }
+
+    // ------------------------------------------------------------ per-thread cell state
+    double x[MAXC][S], zb[MAXC][S], yb[MAXC][S];   // variables and their identity box rows
+    double zg[MAXC][D], yg[MAXC][D];               // dynamics rows of the cell
+    double q[MAXC];                                // q of the position slot
+    double ovb[MIXED ? MAXC : 1][2];               // XY: per-instance |v|, |a| box of the cell
+    double zm[MIXED ? MAXC : 1][6], ym[MIXED ? MAXC : 1][6], ovm[MIXED ? MAXC : 1][6];
+    int cax[MAXC], cst[MAXC];                      // axis and step of the cell (-1: none)
+
+    double qn = 0.0;
+#pragma unroll
+    for (int cc = 0; cc < MAXC; cc++) {
+        const int c = g + 16 * cc;
+        const bool act = c < ncell;
+        const int ax = act ? c / N1 : 0;
+        const int st = act ? c - ax * N1 : -1;
+        cax[cc] = ax; cst[cc] = st;
+        q[cc] = 0.0;
+#pragma unroll
+        for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; yb[cc][k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < D; k++) { zg[cc][k] = 0.0; yg[cc][k] = 0.0; }
+        if (MIXED) {
+            ovb[cc][0] = ovb[cc][1] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { zm[cc][k] = 0.0; ym[cc][k] = 0.0; ovm[cc][k] = 0.0; }
+        }
+        if (act && valid) {
+            q[cc] = P.qw[ax] * a.ref[(size_t)(st * P.ref_stride + P.ref_off[ax]) * a.ref_ld + inst];
+            qn = fmax(qn, fabs(q[cc]));
+            if (MIXED && st >= 1) {
+                const size_t r0 = (size_t)(6 * (st - 1) + 3 * ax) * a.ov_ld + inst;
+                ovb[cc][0] = a.ov_box[r0 + (size_t)a.ov_ld];
+                ovb[cc][1] = a.ov_box[r0 + (size_t)2 * a.ov_ld];
+                if (ax == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) ovm[cc][k] = a.ov_mixed[(size_t)(6 * (st - 1) + k) * a.ov_ld + inst];
+                }
+            }
+            if (a.warm_in) {
+                const size_t w0 = (size_t)(P.axis_base[ax] + st * S) * a.ldw + inst;
+#pragma unroll
+                for (int k = 0; k < S; k++) {
+                    x[cc][k] = a.warm[w0 + (size_t)k * a.ldw];
+                    zb[cc][k] = a.warm[w0 + (size_t)(n_int + k) * a.ldw];
+                    yb[cc][k] = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw];
+                }
+                const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    zg[cc][k] = a.warm[e0 + (size_t)k * a.ldw];
+                    yg[cc][k] = a.warm[e0 + (size_t)(ncell * D + k) * a.ldw];
+                }
+                if (MIXED && ax == 0) {
+                    const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + st * 6) * a.ldw + inst;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        zm[cc][k] = a.warm[m0 + (size_t)k * a.ldw];
+                        ym[cc][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw];
+                    }
+                }
+            }
+        }
+        if (act) {
+#pragma unroll
+            for (int k = 0; k < D; k++) weq[(c * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
+            if (MIXED && ax == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
+            }
+        }
+    }
+    // zero the padding rows of the rhs vector once (they multiply zero operator columns,
+    // but must not hold NaN bit patterns)
+    for (int j = tid; j < n_int * 16; j += 256) v0[j] = 0.0;
+    if (g == 0) red[6 * 16 + t] = 0ull;
+    __syncthreads();
+    qn = wave_gmax(qn);
+    if ((lane >> 4) == 0) lds_max(&red[6 * 16 + t], qn);
+    __syncthreads();
+    qn = __longlong_as_double((long long)red[6 * 16 + t]);
+
+    bool done = !valid;
+    const int max_iter = P.max_iter, check = P.check;
+
+    for (int iter = 1; iter <= max_iter; iter++) {
+        // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
+#pragma unroll
+        for (int cc = 0; cc < MAXC; cc++) {
+            const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
+            if (st >= 0) {
+                double wn[D], wo[D];
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    wo[k] = rho_eq * (zg[cc][k] - yg[cc][k]);
+                    wn[k] = st < N ? weq[((c + 1) * D + k) * 16 + t] : 0.0;
+                }
+                const double *ct = ctab + ax * S * 3;
+                double *out = v0 + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+                double mixc[3] = {0.0, 0.0, 0.0};
+                if (MIXED && st >= 1) {
+                    const double *wm = wmx + (size_t)st * 6 * 16 + t;
+                    const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
+                    if (ax == 0) { mixc[1] = s3 * (w0 + w1) + 0.5 * (w2 - w3); mixc[2] = s2 * (w4 + w5); }
+                    else         { mixc[1] = 0.5 * (w0 - w1) + s3 * (w2 + w3); mixc[2] = s2 * (w4 - w5); }
+                }
+#pragma unroll
+                for (int l = 0; l < D; l++) {
+                    double acc = sigma * x[cc][l] + ct[l * 3] * (zb[cc][l] - yb[cc][l]) - wo[l];
+                    if (l == 0) acc -= q[cc];
+#pragma unroll
+                    for (int k = 0; k <= l; k++) acc += chain_coef<D>(k, l, dt, c2) * wn[k];
+                    if (MIXED && l >= 1) acc += mixc[l];
+                    out[l * 16] = acc;
+                }
+                // input slot (absent at step N: the padding variable stays zero)
+                out[D * 16] = st < N ? sigma * x[cc][D] + ct[D * 3] * (zb[cc][D] - yb[cc][D]) + dt * wn[D - 1]
+                                     : 0.0;
+            }
+        }
+        __syncthreads();
+        // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
+        for (int grp = 0; grp < P.ngrp; grp++) {
+            const int b0 = P.grp_first[grp];
+            const bool two = PAIR && P.grp_cnt[grp] == 2;
+            const double *Mop = P.Mfrag + (size_t)P.grp_op[grp] * nrb * ks * 64 + lane;
+            const double *bp0 = v0 + ((size_t)b0 * nb + (lane >> 4)) * 16 + (lane & 15);
+            const double *bp1 = bp0 + (size_t)nb * 16;
+            d4 acc0[MAXRBW], acc1[PAIR ? MAXRBW : 1];
+#pragma unroll
+            for (int i = 0; i < MAXRBW; i++) acc0[i] = (d4){0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < (PAIR ? MAXRBW : 1); i++) acc1[i] = (d4){0, 0, 0, 0};
+#pragma unroll 4
+            for (int kk = 0; kk < ks; kk++) {
+                const double bf0 = bp0[kk * 64];
+                double bf1 = 0.0;
+                if (PAIR && two) bf1 = bp1[kk * 64];
+#pragma unroll
+                for (int i = 0; i < MAXRBW; i++) {
+                    const int rb = wave + 4 * i;
+                    if (rb < nrb) {
+                        const double af = Mop[((size_t)rb * ks + kk) * 64];
+                        acc0[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf0, acc0[i], 0, 0, 0);
+                        if (PAIR && two)
+                            acc1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf1, acc1[i], 0, 0, 0);
+                    }
+                }
+            }
+            if (!P.separate_xt) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < MAXRBW; i++) {
+                const int rb = wave + 4 * i;
+                if (rb < nrb) {
+                    double *o0 = vx + ((size_t)b0 * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o0[r * 64] = acc0[i][r];
+                    if (PAIR && two) {
+                        double *o1 = o0 + (size_t)nb * 16;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o1[r * 64] = acc1[i][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // -------------------------------------------------------- relaxation, projection, dual
+#pragma unroll
+        for (int cc = 0; cc < MAXC; cc++) {
+            const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
+            if (st >= 0) {
+                const double *xin = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+                const double *ct = ctab + ax * S * 3;
+                double xt[S], xp[S];
+#pragma unroll
+                for (int k = 0; k < S; k++) {
+                    xt[k] = xin[k * 16];
+                    xp[k] = st > 0 ? xin[(k - S) * 16] : 0.0;
+                }
+                // variables and their box rows
+#pragma unroll
+                for (int k = 0; k < S; k++) {
+                    x[cc][k] = alpha * xt[k] + oma * x[cc][k];
+                    const double zr = alpha * xt[k] + oma * zb[cc][k];
+                    const double s = zr + yb[cc][k];
+                    double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
+                    if (MIXED && st >= 1 && (k == 1 || k == 2)) { hi = ovb[cc][k - 1]; lo = -hi; }
+                    const double zn = clampd(s, lo, hi);
+                    yb[cc][k] = s - zn;
+                    zb[cc][k] = zn;
+                }
+                // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    double zt = -xt[k];
+#pragma unroll
+                    for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
+                    if (k == D - 1) zt += dt * xp[D];
+                    double b = 0.0;
+                    if (st == 0 && valid) b = -a.x0[(size_t)(P.x0_row[ax] + k * P.x0_slot) * a.ld + inst];
+                    const double zr = alpha * zt + oma * zg[cc][k];
+                    const double s = zr + yg[cc][k];
+                    yg[cc][k] = s - b;
+                    zg[cc][k] = b;
+                    weq[(c * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+                }
+                if (MIXED && ax == 0 && st >= 1) {
+                    // mixed rows of step st (mpc_12state.cpp:600-630), second axis read from LDS
+                    const double *yin = vx + (size_t)(P.axis_base[1] + st * S) * 16 + t;
+                    const double vxx = xt[1], axx = xt[2], vyy = yin[16], ayy = yin[32];
+                    const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
+                                           -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const double zr = alpha * zt6[k] + oma * zm[cc][k];
+                        const double s = zr + ym[cc][k];
+                        const double zn = clampd(s, -ovm[cc][k], ovm[cc][k]);
+                        ym[cc][k] = s - zn;
+                        zm[cc][k] = zn;
+                        wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * (zn - ym[cc][k]);
+                    }
+                }
+            }
+        }
+        // -------------------------------------------------------- termination check
+        if (iter % check == 0 || iter == max_iter) {
+            __syncthreads();
+            if (g == 0) {
+#pragma unroll
+                for (int k = 0; k < 6; k++) red[k * 16 + t] = 0ull;
+            }
+            // x -> vx, y of the dynamics / mixed rows -> weq / wmx (restored below)
+#pragma unroll
+            for (int cc = 0; cc < MAXC; cc++) {
+                const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
+                if (st >= 0) {
+                    double *xo = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+#pragma unroll
+                    for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
+#pragma unroll
+                    for (int k = 0; k < D; k++) weq[(c * D + k) * 16 + t] = rho_eq * yg[cc][k];
+                    if (MIXED && ax == 0) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * ym[cc][k];
+                    }
+                }
+            }
+            __syncthreads();
+            double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
+#pragma unroll
+            for (int cc = 0; cc < MAXC; cc++) {
+                const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
+                if (st >= 0) {
+                    const double *xin = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+                    const double *ct = ctab + ax * S * 3;
+                    double yn[D], mixc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int k = 0; k < D; k++) yn[k] = st < N ? weq[((c + 1) * D + k) * 16 + t] : 0.0;
+                    if (MIXED && st >= 1) {
+                        const double *wm = wmx + (size_t)st * 6 * 16 + t;
+                        const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
+                        if (ax == 0) { mixc[1] = s3 * (w0 + w1) + 0.5 * (w2 - w3); mixc[2] = s2 * (w4 + w5); }
+                        else         { mixc[1] = 0.5 * (w0 - w1) + s3 * (w2 + w3); mixc[2] = s2 * (w4 - w5); }
+                    }
+                    // dual residual P x + q + A' y on the state slots
+#pragma unroll
+                    for (int l = 0; l < D; l++) {
+                        const double px = l == 0 ? P.pdiag[ax] * x[cc][0] : 0.0;
+                        double aty = ct[l * 3] * yb[cc][l] - rho_eq * yg[cc][l];
+#pragma unroll
+                        for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
+                        if (MIXED && l >= 1) aty += mixc[l];
+                        const double qq = l == 0 ? q[cc] : 0.0;
+                        m_rd = fmax(m_rd, fabs(px + qq + aty));
+                        m_px = fmax(m_px, fabs(px));
+                        m_aty = fmax(m_aty, fabs(aty));
+                    }
+                    if (st < N) { // input slot: P = r I + smooth * D'D (first difference of inputs)
+                        double px = P.r * x[cc][D];
+                        if (P.smooth != 0.0) {
+                            const double um = st > 0 ? xin[(D - S) * 16] : x[cc][D];
+                            const double up = st < N - 1 ? xin[(D + S) * 16] : x[cc][D];
+                            px += P.smooth * ((x[cc][D] - um) + (x[cc][D] - up));
+                        }
+                        const double aty = ct[D * 3] * yb[cc][D] + dt * yn[D - 1];
+                        m_rd = fmax(m_rd, fabs(px + aty));
+                        m_px = fmax(m_px, fabs(px));
+                        m_aty = fmax(m_aty, fabs(aty));
+                    }
+                    // primal residual: box rows (A x = x) ...
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        if (k < D || st < N) {
+                            m_rp = fmax(m_rp, fabs(x[cc][k] - zb[cc][k]));
+                            m_ax = fmax(m_ax, fabs(x[cc][k]));
+                            m_z = fmax(m_z, fabs(zb[cc][k]));
+                        }
+                    }
+                    // ... dynamics rows ...
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        double axv = -x[cc][k];
+                        if (st > 0) {
+#pragma unroll
+                            for (int l = k; l < D; l++) axv += chain_coef<D>(k, l, dt, c2) * xin[(l - S) * 16];
+                            if (k == D - 1) axv += dt * xin[(D - S) * 16];
+                        }
+                        m_rp = fmax(m_rp, fabs(axv - zg[cc][k]));
+                        m_ax = fmax(m_ax, fabs(axv));
+                        m_z = fmax(m_z, fabs(zg[cc][k]));
+                    }
+                    // ... mixed rows
+                    if (MIXED && ax == 0 && st >= 1) {
+                        const double *yin = vx + (size_t)(P.axis_base[1] + st * S) * 16 + t;
+                        const double vxx = x[cc][1], axx = x[cc][2], vyy = yin[16], ayy = yin[32];
+                        const double ax6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
+                                               -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            m_rp = fmax(m_rp, fabs(ax6[k] - zm[cc][k]));
+                            m_ax = fmax(m_ax, fabs(ax6[k]));
+                            m_z = fmax(m_z, fabs(zm[cc][k]));
+                        }
+                    }
+                }
+            }
+            m_rp = wave_gmax(m_rp); m_ax = wave_gmax(m_ax); m_z = wave_gmax(m_z);
+            m_rd = wave_gmax(m_rd); m_px = wave_gmax(m_px); m_aty = wave_gmax(m_aty);
+            if ((lane >> 4) == 0) {
+                lds_max(&red[0 * 16 + t], m_rp); lds_max(&red[1 * 16 + t], m_ax);
+                lds_max(&red[2 * 16 + t], m_z);  lds_max(&red[3 * 16 + t], m_rd);
+                lds_max(&red[4 * 16 + t], m_px); lds_max(&red[5 * 16 + t], m_aty);
+            }
+            __syncthreads();
+            m_rp = __longlong_as_double((long long)red[0 * 16 + t]);
+            m_ax = __longlong_as_double((long long)red[1 * 16 + t]);
+            m_z = __longlong_as_double((long long)red[2 * 16 + t]);
+            m_rd = __longlong_as_double((long long)red[3 * 16 + t]);
+            m_px = __longlong_as_double((long long)red[4 * 16 + t]);
+            m_aty = __longlong_as_double((long long)red[5 * 16 + t]);
+            const double eps_p = P.eps_abs + P.eps_rel * fmax(m_ax, m_z);
+            const double eps_d = P.eps_abs + P.eps_rel * fmax(fmax(m_px, m_aty), qn);
+            const bool conv = (m_rp < eps_p) && (m_rd < eps_d);
+            if (!done && (conv || iter == max_iter)) {
+                done = true;
+                // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551)
+                for (int cc = 0; cc < MAXC; cc++) {
+                    const int c = g + 16 * cc;
+                    if (c < ncell) {
+                        const int ax = c / N1, st = c - ax * N1;
+                        const double *xs = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+                        for (int k = 0; k < D; k++)
+                            a.X[(size_t)(st * P.X_stride + P.X_off[ax] + k * P.X_slot) * a.ld + inst] = xs[k * 16];
+                        if (st < N) a.U[(size_t)(st * P.U_stride + P.U_off[ax]) * a.ld + inst] = xs[D * 16];
+                    }
+                }
+                if (g == 0) {
+                    if (a.status) a.status[inst] = conv ? TG_DEV_SOLVED : TG_DEV_MAX_ITER;
+                    if (a.iters) a.iters[inst] = iter;
+                    if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.ld + inst] = m_rd; }
+                }
+                if (a.warm_out) {
+#pragma unroll
+                    for (int cc = 0; cc < MAXC; cc++) {
+                        const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
+                        if (st >= 0) {
+                            const size_t w0 = (size_t)(P.axis_base[ax] + st * S) * a.ldw + inst;
+#pragma unroll
+                            for (int k = 0; k < S; k++) {
+                                a.warm[w0 + (size_t)k * a.ldw] = x[cc][k];
+                                a.warm[w0 + (size_t)(n_int + k) * a.ldw] = zb[cc][k];
+                                a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] = yb[cc][k];
+                            }
+                            const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
+#pragma unroll
+                            for (int k = 0; k < D; k++) {
+                                a.warm[e0 + (size_t)k * a.ldw] = zg[cc][k];
+                                a.warm[e0 + (size_t)(ncell * D + k) * a.ldw] = yg[cc][k];
+                            }
+                            if (MIXED && ax == 0) {
+                                const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + st * 6) * a.ldw + inst;
+#pragma unroll
+                                for (int k = 0; k < 6; k++) {
+                                    a.warm[m0 + (size_t)k * a.ldw] = zm[cc][k];
+                                    a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw] = ym[cc][k];
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (__syncthreads_and(done ? 1 : 0)) break;
+            // weq / wmx held y during the check: restore w = rho (z - y/rho)
+#pragma unroll
+            for (int cc = 0; cc < MAXC; cc++) {
+                const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
+                if (st >= 0) {
+#pragma unroll
+                    for (int k = 0; k < D; k++) weq[(c * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
+                    if (MIXED && ax == 0) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------- full q, l, u per instance
+// one thread per (row block, instance); rows of q, l, u in the reference's ordering
+__global__ __launch_bounds__(256) void assemble_kernel(const AsmDev P, const BatchArgs a,
+                                                        double *__restrict__ q,
+                                                        double *__restrict__ l,
+                                                        double *__restrict__ u)
+{
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= a.B) return;
+    const int r0 = blockIdx.y * P.rows_per_block;
+    const int r1 = min(r0 + P.rows_per_block, max(P.n, P.m));
+    for (int r = r0; r < r1; r++) {
+        if (r < P.n && q) {
+            double v = 0.0;
+            const int rr = P.q_ref_row[r];
+            if (rr >= 0) v = P.q_w[r] * a.ref[(size_t)rr * a.ref_ld + inst];
+            q[(size_t)r * a.ld + inst] = v;
+        }
+        if (r < P.m && l) {
+            double lo = P.l_t[r], hi = P.u_t[r];
+            const int xr = P.x0_row[r];
+            if (xr >= 0) { lo = -a.x0[(size_t)xr * a.ld + inst]; hi = lo; }
+            const int ob = P.ov_box[r];
+            if (ob >= 0) { hi = a.ov_box[(size_t)ob * a.ov_ld + inst]; lo = -1.0 * hi; }
+            const int om = P.ov_mixed[r];
+            if (om >= 0) { hi = a.ov_mixed[(size_t)om * a.ov_ld + inst]; lo = -1.0 * hi; }
+            l[(size_t)r * a.ld + inst] = lo;
+            u[(size_t)r * a.ld + inst] = hi;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- computeXYBounds
+// X holds the Z-stage solution in rows 12 i + 6..8.  Output rows: step i-1 (i = 1..N), 6 each.
+__global__ __launch_bounds__(256) void xy_bounds_kernel(int B, int ld, int N, double xy_max_vel,
+                                                         double xy_max_accel, double z_max_accel,
+                                                         const double *__restrict__ X,
+                                                         double *__restrict__ xy_max,
+                                                         double *__restrict__ mixed_max)
+{
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y + 1;
+    if (inst >= B || i > N) return;
+    const double v_zt = X[(size_t)(12 * i + 7) * ld + inst];
+    double vb;
+    if (v_zt < 0) {
+        vb = xy_max_vel;
+    } else {
+        const double a_zt = X[(size_t)(12 * i + 8) * ld + inst];
+        const double d = a_zt / z_max_accel;
+        vb = xy_max_vel * 0.9;
+        if ((1 - d * d) >= 0) vb = xy_max_vel * sqrt(1 - d * d);
+    }
+    double *b = xy_max + (size_t)6 * (i - 1) * ld + inst;
+    double *mx = mixed_max + (size_t)6 * (i - 1) * ld + inst;
+    b[0] = TG_DEV_INFTY; b[(size_t)ld] = vb; b[(size_t)2 * ld] = xy_max_accel;
+    b[(size_t)3 * ld] = TG_DEV_INFTY; b[(size_t)4 * ld] = vb; b[(size_t)5 * ld] = xy_max_accel;
+    mx[0] = vb; mx[(size_t)ld] = vb; mx[(size_t)2 * ld] = vb; mx[(size_t)3 * ld] = vb;
+    mx[(size_t)4 * ld] = xy_max_accel; mx[(size_t)5 * ld] = xy_max_accel;
+}
+
+// ---------------------------------------------------------------- computeYawRefTrajectory
+__global__ __launch_bounds__(256) void yaw_ref_kernel(int B, int ld, int N,
+                                                       const double *__restrict__ ref,
+                                                       const double *__restrict__ X,
+                                                       double *__restrict__ yaw_ref)
+{
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (inst >= B || i > N) return;
+    const double xt = ref[(size_t)(12 * i + 0) * ld + inst], yt = ref[(size_t)(12 * i + 3) * ld + inst];
+    const double xi = X[(size_t)(12 * i + 0) * ld + inst], yi = X[(size_t)(12 * i + 3) * ld + inst];
+    yaw_ref[(size_t)i * ld + inst] = atan2(yt - yi, xt - xi);
+}
+
+// ---------------------------------------------------------------- host-callable launchers
+size_t admm_lds_bytes(const StageDev &P)
+{
+    const int S = P.D + 1, ncell = P.nax * (P.N + 1);
+    size_t rows = (size_t)(P.separate_xt ? 2 : 1) * P.n_int + (size_t)ncell * P.D + (P.mixed ? (size_t)(P.N + 1) * 6 : 0);
+    return rows * 16 * sizeof(double) + (size_t)P.nax * S * 3 * sizeof(double) + 7 * 16 * sizeof(double);
+}
+
+template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR>
+static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
+{
+    auto kern = admm_kernel<D, NAX, MIXED, MAXC, MAXRBW, PAIR>;
+    const size_t lds_bytes = admm_lds_bytes(P);
+    hipError_t e = hipFuncSetAttribute((const void *)kern,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    const int grid = (a.B + kTileDev - 1) / kTileDev;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, P, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why)
+{
+    const int ncell = P.nax * (P.N + 1);
+    const int needc = (ncell + 15) / 16, needr = (P.nrb + 3) / 4;
+    if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
+    if (P.D == 2 && P.nax == 3 && !P.mixed) {
+        if (needc <= 4 && needr <= 1) return launch_admm_t<2, 3, false, 4, 1, true>(P, a, s);
+        if (needc <= 10 && needr <= 3) return launch_admm_t<2, 3, false, 10, 3, true>(P, a, s);
+    } else if (P.D == 3 && P.nax == 2 && P.mixed) {
+        if (needc <= 3 && needr <= 3) return launch_admm_t<3, 2, true, 3, 3, false>(P, a, s);
+        if (needc <= 7 && needr <= 7) return launch_admm_t<3, 2, true, 7, 7, false>(P, a, s);
+    } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
+        if (needc <= 2 && needr <= 2) return launch_admm_t<3, 1, false, 2, 2, false>(P, a, s);
+        if (needc <= 4 && needr <= 4) return launch_admm_t<3, 1, false, 4, 4, false>(P, a, s);
+    }
+    *why = "horizon too long for the compiled kernel variants";
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_assemble(const AsmDev &P, const BatchArgs &a, double *q, double *l, double *u,
+                           hipStream_t s)
+{
+    const int rows = P.n > P.m ? P.n : P.m;
+    dim3 grid((a.B + 255) / 256, (rows + P.rows_per_block - 1) / P.rows_per_block);
+    hipLaunchKernelGGL(assemble_kernel, grid, dim3(256), 0, s, P, a, q, l, u);
+    return hipGetLastError();
+}
+
+hipError_t launch_xy_bounds(int B, int ld, int N, double xy_max_vel, double xy_max_accel,
+                            double z_max_accel, const double *X, double *xy_max, double *mixed_max,
+                            hipStream_t s)
+{
+    dim3 grid((B + 255) / 256, N);
+    hipLaunchKernelGGL(xy_bounds_kernel, grid, dim3(256), 0, s, B, ld, N, xy_max_vel, xy_max_accel,
+                       z_max_accel, X, xy_max, mixed_max);
+    return hipGetLastError();
+}
+
+hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
+                          hipStream_t s)
+{
+    dim3 grid((B + 255) / 256, N + 1);
+    hipLaunchKernelGGL(yaw_ref_kernel, grid, dim3(256), 0, s, B, ld, N, ref, X, yaw_ref);
+    return hipGetLastError();
+}
+
+} // namespace tg

@@ -1,0 +1,60 @@
+// Plain structs shared by the host code and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace tg {
+
+constexpr int kTileDev = 16;            // instances per workgroup = MFMA f64 16x16x4 columns
+constexpr double TG_DEV_INFTY = 1e30;   // OsqpEigen::INFTY
+constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2;
+constexpr int kMaxAxes = 3, kMaxSlots = 4;
+
+// One QP stage as the ADMM kernel sees it.  Every axis of the model is a chain of
+// integrators of order D (6-DOF: D = 2, states p,v, input a; 12-state stages: D = 3,
+// states p,v,a, input j).  A "cell" is one horizon step of one axis: slots 0..D-1 are its
+// states, slot D its input (absent at step N).  Internal variable index of
+// (axis a, step i, slot k) = axis_base[a] + i*(D+1) + k.
+struct StageDev {
+    int N, D, nax, mixed;        // horizon, chain order, axes, XY mixed rows present
+    int n_int, nb, nrb, ks;      // padded size of all blocks, block size, row blocks, k steps
+    int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
+    int axis_base[kMaxAxes];
+    int separate_xt;
+    const double *Mfrag;         // [nops][nrb][ks][64] operator fragments, MFMA A-operand order
+    double dt, c2;               // c2 = dt^2/2 (position <- acceleration coupling, D = 3)
+    double qw[kMaxAxes];         // q(position slot) = qw * ref            (qw = -state weight)
+    double pdiag[kMaxAxes];      // P diagonal on the position slot
+    double r, smooth;            // P on inputs: r*I + smooth * D'D (smooth = 0: off)
+    double rho_eq;               // dynamics rows
+    double rho_box[kMaxAxes][kMaxSlots], lb[kMaxAxes][kMaxSlots], ub[kMaxAxes][kMaxSlots];
+    double rho_mx[6], ub_mx[6];  // XY mixed rows (symmetric bounds)
+    // where the stage reads / writes the model-level arrays
+    int x0_row[kMaxAxes];        // row of slot 0 of the axis in x0 (slots are consecutive rows)
+    int ref_stride, ref_off[kMaxAxes]; // ref row of (step i, axis a) position = i*ref_stride + ref_off[a]
+    int X_stride, X_off[kMaxAxes];     // X row of (step i, axis a, slot k) = i*X_stride + X_off[a] + k*X_slot
+    int X_slot;                  // row distance between slots of one axis in X (6-DOF: 3, else 1)
+    int x0_slot;                 // same for x0
+    int U_stride, U_off[kMaxAxes];
+    double sigma, alpha, eps_abs, eps_rel;
+    int max_iter, check;
+};
+
+// reference-ordered tables for the assembly kernel
+struct AsmDev {
+    int n, m, rows_per_block;
+    const double *q_w, *l_t, *u_t;
+    const int32_t *q_ref_row, *x0_row, *ov_box, *ov_mixed;
+};
+
+// per-call arrays (device, structure-of-arrays, instance-minor)
+struct BatchArgs {
+    int B, ld, ref_ld, ov_ld, ldw;
+    const double *x0, *ref, *ov_box, *ov_mixed;
+    double *X, *U;
+    int *status, *iters;
+    double *res;             // optional [2][ld]: primal / dual residual at exit
+    int warm_in, warm_out;
+    double *warm;            // [warm_rows][ldw] iterates kept between calls
+};
+
+} // namespace tg

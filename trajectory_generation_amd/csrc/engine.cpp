@@ -1,0 +1,594 @@
+// C ABI of the batched MPC engine (include/tg_mpc.h): handles, device residency of the
+// shared QP data, kernel sequencing for MPC::mpcLoop (mpc_6dof.cpp:616-649) and
+// MPC12STATE::mpcLoop (mpc_12state.cpp:1374-1453).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "stage_problem.hpp"
+
+namespace tg {
+hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why);
+hipError_t launch_assemble(const AsmDev &P, const BatchArgs &a, double *q, double *l, double *u,
+                           hipStream_t s);
+hipError_t launch_xy_bounds(int B, int ld, int N, double xy_max_vel, double xy_max_accel,
+                            double z_max_accel, const double *X, double *xy_max, double *mixed_max,
+                            hipStream_t s);
+hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
+                          hipStream_t s);
+} // namespace tg
+
+using namespace tg;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return fail(TG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));    \
+    } while (0)
+
+// ---------------------------------------------------------------- kernel timing
+static bool g_timing = false;
+static double g_admm_ms = 0.0, g_iters_total = 0.0;
+static int g_admm_launches = 0;
+struct PendingEvent { hipEvent_t a, b; };
+static std::vector<PendingEvent> g_pending;
+
+static void drain_events()
+{
+    for (auto &p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_admm_ms += ms; g_admm_launches++;
+        }
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    g_pending.clear();
+}
+
+// ---------------------------------------------------------------- device residency of one stage
+template <class T> static int upload(const std::vector<T> &h, T **d)
+{
+    *d = nullptr;
+    size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void **)d, bytes));
+    if (!h.empty()) HIP_TRY(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return TG_OK;
+}
+
+struct DevStage {
+    StageProblem sp;
+    StageDev dev{};
+    AsmDev adev{};
+    double *d_Mfrag = nullptr;
+    double *d_qw = nullptr, *d_lt = nullptr, *d_ut = nullptr;
+    int32_t *d_qrr = nullptr, *d_x0r = nullptr, *d_ovb = nullptr, *d_ovm = nullptr;
+    // warm-start iterates of the instance slots
+    double *d_warm = nullptr; int warm_cap = 0; bool warm_valid = false; int warm_B = 0;
+
+    int init(const StageModel &mdl, const tg_solver_opts &o, double rho)
+    {
+        std::string err;
+        if (!build_stage(mdl, rho, o.sigma, sp, err)) return fail(TG_E_NUMERIC, err);
+        int rc;
+        if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
+        if ((rc = upload(sp.q_w, &d_qw))) return rc;
+        if ((rc = upload(sp.l_t, &d_lt))) return rc;
+        if ((rc = upload(sp.u_t, &d_ut))) return rc;
+        if ((rc = upload(sp.q_ref_row, &d_qrr))) return rc;
+        if ((rc = upload(sp.asm_x0_row, &d_x0r))) return rc;
+        if ((rc = upload(sp.asm_ov_box, &d_ovb))) return rc;
+        if ((rc = upload(sp.asm_ov_mixed, &d_ovm))) return rc;
+        const bool six = mdl.family == TG_FAM_6DOF, xy = mdl.family == TG_FAM_XY;
+        dev.N = mdl.N; dev.D = sp.D; dev.nax = sp.nax; dev.mixed = mdl.n_mixed ? 1 : 0;
+        dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = sp.nb / 16; dev.ks = sp.nb / 4;
+        // groups of up to two adjacent blocks that share an operator
+        dev.ngrp = 0;
+        for (int b = 0; b < sp.nblk;) {
+            int cnt = (b + 1 < sp.nblk && sp.op_of_block[b + 1] == sp.op_of_block[b]) ? 2 : 1;
+            dev.grp_first[dev.ngrp] = b; dev.grp_cnt[dev.ngrp] = cnt; dev.grp_op[dev.ngrp] = sp.op_of_block[b];
+            dev.ngrp++; b += cnt;
+        }
+        dev.Mfrag = d_Mfrag;
+        dev.dt = mdl.Ad[1] != 0.0 ? mdl.Ad[1] : mdl.Ad[3];   // Ad(0,1) (triple integrator) or Ad(0,3) (6-DOF)
+        dev.c2 = six ? 0.0 : mdl.Ad[2];
+        dev.r = mdl.r; dev.smooth = mdl.smoothing ? mdl.smooth_w : 0.0;
+        dev.rho_eq = sp.rho_eq;
+        dev.X_slot = six ? 3 : 1; dev.x0_slot = six ? 3 : 1;
+        dev.ref_stride = mdl.ref_stride; dev.X_stride = mdl.X_stride; dev.U_stride = mdl.U_stride;
+        for (int a = 0; a < sp.nax; a++) {
+            const int pc = six ? a : (xy ? 3 * a : 0);  // position component of the axis
+            dev.axis_base[a] = sp.axis_base[a];
+            dev.qw[a] = -1.0 * mdl.qdiag[pc]; dev.pdiag[a] = mdl.qdiag[pc];
+            dev.x0_row[a] = mdl.x0_row[pc];
+            dev.ref_off[a] = mdl.ref_off + (mdl.ref_pos_only ? 0 : pc);
+            dev.X_off[a] = mdl.X_off + pc; dev.U_off[a] = mdl.U_off + a;
+            for (int k = 0; k <= sp.D; k++) {
+                dev.rho_box[a][k] = sp.rho_box[a][k]; dev.lb[a][k] = sp.lb[a][k]; dev.ub[a][k] = sp.ub[a][k];
+            }
+        }
+        for (int k = 0; k < 6; k++) { dev.rho_mx[k] = sp.rho_mx[k]; dev.ub_mx[k] = sp.ub_mx[k]; }
+        // a second on-chip vector for xt saves one barrier per block group; take it when two
+        // workgroups still fit a CU's 160 KiB of LDS
+        {
+            const int ncell = sp.nax * (mdl.N + 1);
+            size_t rows2 = (size_t)2 * sp.n_int + (size_t)ncell * sp.D + (dev.mixed ? (size_t)(mdl.N + 1) * 6 : 0);
+            dev.separate_xt = rows2 * 16 * 8 + 1024 <= 80 * 1024 ? 1 : 0;
+        }
+        dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel;
+        dev.max_iter = o.max_iter; dev.check = o.check_termination;
+        adev.n = sp.n; adev.m = sp.m; adev.rows_per_block = 32;
+        adev.q_w = d_qw; adev.l_t = d_lt; adev.u_t = d_ut; adev.q_ref_row = d_qrr;
+        adev.x0_row = d_x0r; adev.ov_box = d_ovb; adev.ov_mixed = d_ovm;
+        return TG_OK;
+    }
+    void release()
+    {
+        hipFree(d_Mfrag);
+        hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
+        hipFree(d_ovm); hipFree(d_warm);
+    }
+    size_t warm_rows() const
+    {
+        return (size_t)3 * sp.n_int + (size_t)2 * sp.nax * (sp.mdl.N + 1) * sp.D + (size_t)12 * (sp.mdl.N + 1);
+    }
+    int ensure_warm(int B)
+    {
+        int cap = (B + 15) / 16 * 16;
+        if (cap <= warm_cap) return TG_OK;
+        hipFree(d_warm); d_warm = nullptr; warm_cap = 0; warm_valid = false;
+        size_t rows = warm_rows();
+        HIP_TRY(hipMalloc((void **)&d_warm, rows * cap * sizeof(double)));
+        warm_cap = cap;
+        return TG_OK;
+    }
+    // one batched ADMM solve of this stage
+    int solve(BatchArgs a, int warm, hipStream_t s)
+    {
+        a.warm_in = 0; a.warm_out = 0; a.ldw = 0;
+        a.warm = nullptr;
+        if (warm) {
+            int rc = ensure_warm(a.B);
+            if (rc) return rc;
+            a.ldw = warm_cap;
+            a.warm = d_warm;
+            a.warm_in = (warm_valid && warm_B >= a.B) ? 1 : 0;
+            a.warm_out = 1;
+        }
+        const char *why = "";
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_timing) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, s)); }
+        hipError_t e = launch_admm(dev, a, s, &why);
+        if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
+                                         std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
+        if (g_timing) { HIP_TRY(hipEventRecord(e1, s)); g_pending.push_back({e0, e1}); }
+        if (warm) { warm_valid = true; warm_B = a.B; }
+        return TG_OK;
+    }
+    int get(int which, double *out) const
+    {
+        const int n = sp.n, m = sp.m, nx = sp.mdl.nx, nu = sp.mdl.nu;
+        auto copy = [&](const std::vector<double> &v) { std::memcpy(out, v.data(), v.size() * sizeof(double)); };
+        switch (which) {
+        case TG_MAT_P: copy(sp.P); break;
+        case TG_MAT_A: copy(sp.A); break;
+        case TG_MAT_KINV: copy(sp.Kinv); break;
+        case TG_VEC_L: copy(sp.l_t); break;
+        case TG_VEC_U: copy(sp.u_t); break;
+        case TG_VEC_RHO: copy(sp.rho_vec); break;
+        case TG_MAT_AD: std::memcpy(out, sp.mdl.Ad, sizeof(double) * nx * nx); break;
+        case TG_MAT_BD: std::memcpy(out, sp.mdl.Bd, sizeof(double) * nx * nu); break;
+        case TG_MAT_Q:
+            std::memset(out, 0, sizeof(double) * nx * nx);
+            for (int a = 0; a < nx; a++) out[a * nx + a] = sp.mdl.qdiag[a];
+            break;
+        case TG_MAT_R:
+            std::memset(out, 0, sizeof(double) * nu * nu);
+            for (int a = 0; a < nu; a++) out[a * nu + a] = sp.mdl.r;
+            break;
+        default: return fail(TG_E_ARG, "unknown matrix id");
+        }
+        (void)n; (void)m;
+        return TG_OK;
+    }
+};
+
+// growable device scratch for the host-pointer entry points
+struct HostStaging {
+    double *d = nullptr; size_t cap = 0;
+    int *di = nullptr; size_t capi = 0;
+    int ensure(size_t doubles, size_t ints)
+    {
+        if (doubles > cap) { hipFree(d); d = nullptr; cap = 0; HIP_TRY(hipMalloc((void **)&d, doubles * sizeof(double))); cap = doubles; }
+        if (ints > capi) { hipFree(di); di = nullptr; capi = 0; HIP_TRY(hipMalloc((void **)&di, ints * sizeof(int))); capi = ints; }
+        return TG_OK;
+    }
+    void release() { hipFree(d); hipFree(di); }
+};
+
+static void to_soa(const double *aos, int B, int rows, int ld, std::vector<double> &soa)
+{
+    soa.assign((size_t)rows * ld, 0.0);
+    for (int b = 0; b < B; b++)
+        for (int r = 0; r < rows; r++) soa[(size_t)r * ld + b] = aos[(size_t)b * rows + r];
+}
+static void from_soa(const std::vector<double> &soa, int B, int rows, int ld, double *aos)
+{
+    for (int b = 0; b < B; b++)
+        for (int r = 0; r < rows; r++) aos[(size_t)b * rows + r] = soa[(size_t)r * ld + b];
+}
+
+static int check_opts(const tg_solver_opts &o)
+{
+    if (!(o.sigma > 0) || !(o.alpha > 0 && o.alpha < 2) || !(o.eps_abs >= 0) || !(o.eps_rel >= 0) ||
+        o.max_iter < 1 || o.check_termination < 1)
+        return fail(TG_E_ARG, "invalid solver options");
+    return TG_OK;
+}
+
+extern "C" {
+
+void tg_default_opts(tg_solver_opts *o)
+{
+    o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
+    o->max_iter = 4000; o->check_termination = 25;
+}
+const char *tg_last_error(void) { return g_err.c_str(); }
+int tg_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+
+int tg_copy_to_host(void *dst, const void *d_src, unsigned long long bytes)
+{
+    if (!dst || !d_src) return fail(TG_E_ARG, "null pointer");
+    HIP_TRY(hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+void tg_timing_enable(int on) { g_timing = on != 0; }
+int tg_timing_read(double *ms, int *launches, double *iters_total, int reset)
+{
+    drain_events();
+    if (ms) *ms = g_admm_ms;
+    if (launches) *launches = g_admm_launches;
+    if (iters_total) *iters_total = g_iters_total;
+    if (reset) { g_admm_ms = 0; g_admm_launches = 0; g_iters_total = 0; }
+    return TG_OK;
+}
+
+// ================================================================ 6-DOF
+struct tg_mpc6 {
+    tg_mpc6_params p; tg_solver_opts o; int device;
+    DevStage st; HostStaging hs;
+};
+
+int tg_mpc6_create(const tg_mpc6_params *p, const tg_solver_opts *o, int device, tg_mpc6 **out)
+{
+    if (!p || !out) return fail(TG_E_ARG, "null argument");
+    *out = nullptr;
+    if (p->N < 1 || !(p->dt > 0)) return fail(TG_E_ARG, "N must be >= 1 and dt > 0");
+    if (p->state_weight < 0 || p->input_weight < 0 || p->smooth_input_weight < 0)
+        return fail(TG_E_ARG, "weights must be >= 0");
+    for (int a = 0; a < 3; a++)
+        if (p->max_vel[a] < 0 || p->max_accel[a] < 0) return fail(TG_E_ARG, "limits must be >= 0");
+    tg_solver_opts oo;
+    if (o) oo = *o; else tg_default_opts(&oo);
+    int rc = check_opts(oo);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    tg_mpc6 *h = new tg_mpc6();
+    h->p = *p; h->o = oo; h->device = device;
+    rc = h->st.init(model_6dof(*p), oo, oo.rho);
+    if (rc) { h->st.release(); delete h; return rc; }
+    *out = h;
+    return TG_OK;
+}
+
+void tg_mpc6_destroy(tg_mpc6 *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    h->st.release(); h->hs.release();
+    delete h;
+}
+
+int tg_mpc6_solve_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm, void *stream)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
+    if (B == 0) return TG_OK;
+    if (!d_x0 || !d_ref || !d_X || !d_U) return fail(TG_E_ARG, "null device array");
+    HIP_TRY(hipSetDevice(h->device));
+    BatchArgs a{};
+    a.B = B; a.ld = ld; a.ref_ld = ld; a.ov_ld = 0;
+    a.x0 = d_x0; a.ref = d_ref; a.ov_box = nullptr; a.ov_mixed = nullptr;
+    a.X = d_X; a.U = d_U; a.status = d_status; a.iters = d_iters; a.res = nullptr;
+    return h->st.solve(a, warm, (hipStream_t)stream);
+}
+
+int tg_mpc6_solve_host(tg_mpc6 *h, int B, const double *x0, const double *ref, double *X, double *U,
+                       int *status, int *iters, int warm)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0) return fail(TG_E_ARG, "B < 0");
+    if (B == 0) return TG_OK;
+    if (!x0 || !ref || !X || !U) return fail(TG_E_ARG, "null host array");
+    HIP_TRY(hipSetDevice(h->device));
+    const int N = h->p.N, ld = (B + 15) / 16 * 16;
+    const int rx = 6, rr = 6 * (N + 1), rX = 6 * (N + 1), rU = 3 * N;
+    int rc = h->hs.ensure((size_t)(rx + rr + rX + rU) * ld, (size_t)2 * ld);
+    if (rc) return rc;
+    double *dx0 = h->hs.d, *dref = dx0 + (size_t)rx * ld, *dX = dref + (size_t)rr * ld, *dU = dX + (size_t)rX * ld;
+    std::vector<double> tmp;
+    to_soa(x0, B, rx, ld, tmp);
+    HIP_TRY(hipMemcpy(dx0, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    to_soa(ref, B, rr, ld, tmp);
+    HIP_TRY(hipMemcpy(dref, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    rc = tg_mpc6_solve_batch(h, B, ld, dx0, dref, dX, dU, h->hs.di, h->hs.di + ld, warm, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    tmp.resize((size_t)rX * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), dX, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    from_soa(tmp, B, rX, ld, X);
+    tmp.resize((size_t)rU * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), dU, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    from_soa(tmp, B, rU, ld, U);
+    if (status) HIP_TRY(hipMemcpy(status, h->hs.di, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (iters) HIP_TRY(hipMemcpy(iters, h->hs.di + ld, sizeof(int) * B, hipMemcpyDeviceToHost));
+    return TG_OK;
+}
+
+int tg_mpc6_assemble_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                           double *d_q, double *d_l, double *d_u, void *stream)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
+    if (B == 0) return TG_OK;
+    if (!d_x0 || !d_ref) return fail(TG_E_ARG, "null device array");
+    if ((d_l == nullptr) != (d_u == nullptr)) return fail(TG_E_ARG, "l and u go together");
+    HIP_TRY(hipSetDevice(h->device));
+    BatchArgs a{};
+    a.B = B; a.ld = ld; a.ref_ld = ld; a.x0 = d_x0; a.ref = d_ref;
+    HIP_TRY(launch_assemble(h->st.adev, a, d_q, d_l, d_u, (hipStream_t)stream));
+    return TG_OK;
+}
+
+int tg_mpc6_reset_warm(tg_mpc6 *h) { if (!h) return fail(TG_E_ARG, "null handle"); h->st.warm_valid = false; return TG_OK; }
+int tg_mpc6_dims(const tg_mpc6 *h, int *n, int *m)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (n) *n = h->st.sp.n;
+    if (m) *m = h->st.sp.m;
+    return TG_OK;
+}
+int tg_mpc6_get(const tg_mpc6 *h, int which, double *out)
+{
+    if (!h || !out) return fail(TG_E_ARG, "null argument");
+    return h->st.get(which, out);
+}
+double tg_mpc6_rho(const tg_mpc6 *h) { return h ? h->st.sp.rho : 0.0; }
+
+// ================================================================ 12-state
+struct tg_mpc12 {
+    tg_mpc12_params p; tg_solver_opts o; int device;
+    DevStage st[4]; // indexed by TG_FAM_*; [0] unused
+    HostStaging hs;
+    double *d_inter = nullptr; int inter_ld = 0; // xy_max [6N] | mixed_max [6N] | yaw_ref [N+1]
+    int ensure_inter(int ld)
+    {
+        if (ld <= inter_ld) return TG_OK;
+        hipFree(d_inter); d_inter = nullptr; inter_ld = 0;
+        HIP_TRY(hipMalloc((void **)&d_inter, (size_t)(13 * p.N + 1) * ld * sizeof(double)));
+        inter_ld = ld;
+        return TG_OK;
+    }
+    double *xy_max() { return d_inter; }
+    double *mixed_max() { return d_inter + (size_t)6 * p.N * inter_ld; }
+    double *yaw_ref() { return d_inter + (size_t)12 * p.N * inter_ld; }
+};
+
+int tg_mpc12_create(const tg_mpc12_params *p, const tg_solver_opts *o, const double *rho_xyz,
+                    int device, tg_mpc12 **out)
+{
+    if (!p || !out) return fail(TG_E_ARG, "null argument");
+    *out = nullptr;
+    if (p->N < 1 || !(p->dt > 0)) return fail(TG_E_ARG, "N must be >= 1 and dt > 0");
+    const double nonneg[] = {p->xy_state_weight, p->z_state_weight, p->yaw_state_weight, p->xy_input_weight,
+                             p->z_input_weight, p->yaw_input_weight, p->xy_smooth_input_weight,
+                             p->z_smooth_input_weight, p->yaw_smooth_input_weight, p->xy_max_vel, p->z_max_vel,
+                             p->yaw_max_vel, p->xy_max_accel, p->z_max_accel, p->yaw_max_accel, p->xy_max_jerk,
+                             p->z_max_jerk, p->yaw_max_jerk};
+    for (double v : nonneg) if (v < 0) return fail(TG_E_ARG, "weights and limits must be >= 0");
+    tg_solver_opts oo;
+    if (o) oo = *o; else tg_default_opts(&oo);
+    int rc = check_opts(oo);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    tg_mpc12 *h = new tg_mpc12();
+    h->p = *p; h->o = oo; h->device = device;
+    const int fams[3] = {TG_FAM_XY, TG_FAM_Z, TG_FAM_YAW};
+    for (int k = 0; k < 3; k++) {
+        double rho = rho_xyz ? rho_xyz[k] : oo.rho;
+        rc = h->st[fams[k]].init(model_12(*p, fams[k]), oo, rho);
+        if (rc) { tg_mpc12_destroy(h); return rc; }
+    }
+    *out = h;
+    return TG_OK;
+}
+
+void tg_mpc12_destroy(tg_mpc12 *h)
+{
+    if (!h) return;
+    hipSetDevice(h->device);
+    for (int f = 1; f <= 3; f++) h->st[f].release();
+    h->hs.release(); hipFree(h->d_inter);
+    delete h;
+}
+
+static int mpc12_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0, const double *d_ref,
+                       double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s)
+{
+    int rc = h->ensure_inter(ld);
+    if (rc) return rc;
+    const tg_mpc12_params &p = h->p;
+    BatchArgs a{};
+    a.B = B; a.ld = ld; a.ref_ld = ld; a.ov_ld = h->inter_ld;
+    a.x0 = d_x0; a.ref = d_ref; a.X = d_X; a.U = d_U; a.res = nullptr;
+    const int slot = stage == TG_FAM_Z ? 0 : stage == TG_FAM_XY ? 1 : 2;
+    a.status = d_status ? d_status + (size_t)slot * ld : nullptr;
+    a.iters = d_iters ? d_iters + (size_t)slot * ld : nullptr;
+    if (stage == TG_FAM_XY) {
+        // computeXYBounds from the Z solution already in X, then updateXYQP + solve
+        HIP_TRY(launch_xy_bounds(B, ld, p.N, p.xy_max_vel, p.xy_max_accel, p.z_max_accel, d_X,
+                                 h->xy_max(), h->mixed_max(), s));
+        // the bound arrays use the handle's leading dimension
+        if (h->inter_ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
+        a.ov_box = h->xy_max(); a.ov_mixed = h->mixed_max();
+    } else if (stage == TG_FAM_YAW) {
+        if (h->inter_ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
+        HIP_TRY(launch_yaw_ref(B, ld, p.N, d_ref, d_X, h->yaw_ref(), s));
+        a.ref = h->yaw_ref(); a.ref_ld = h->inter_ld;
+    }
+    return h->st[stage].solve(a, warm, s);
+}
+
+static int mpc12_check(tg_mpc12 *h, int B, int ld, const void *a, const void *b, const void *c, const void *d)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
+    if (B > 0 && (!a || !b || !c || !d)) return fail(TG_E_ARG, "null device array");
+    return TG_OK;
+}
+
+int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                         double *d_X, double *d_U, int *d_status, int *d_iters, int warm, void *stream)
+{
+    int rc = mpc12_check(h, B, ld, d_x0, d_ref, d_X, d_U);
+    if (rc || B == 0) return rc;
+    HIP_TRY(hipSetDevice(h->device));
+    // keep one leading dimension for the intermediates of a handle
+    if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = mpc12_stage(h, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s))) return rc;
+    if ((rc = mpc12_stage(h, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s))) return rc;
+    if ((rc = mpc12_stage(h, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s))) return rc;
+    return TG_OK;
+}
+
+int tg_mpc12_solve_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0, const double *d_ref,
+                         double *d_X, double *d_U, int *d_status, int *d_iters, void *stream)
+{
+    int rc = mpc12_check(h, B, ld, d_x0, d_ref, d_X, d_U);
+    if (rc || B == 0) return rc;
+    if (stage < TG_FAM_XY || stage > TG_FAM_YAW) return fail(TG_E_ARG, "stage must be XY, Z or YAW");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
+    return mpc12_stage(h, stage, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, (hipStream_t)stream);
+}
+
+int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref, double *X, double *U,
+                        int *status, int *iters, int warm)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0) return fail(TG_E_ARG, "B < 0");
+    if (B == 0) return TG_OK;
+    if (!x0 || !ref || !X || !U) return fail(TG_E_ARG, "null host array");
+    HIP_TRY(hipSetDevice(h->device));
+    const int N = h->p.N, ld = (B + 15) / 16 * 16;
+    const int rx = 12, rr = 12 * (N + 1), rX = 12 * (N + 1), rU = 4 * N;
+    int rc = h->hs.ensure((size_t)(rx + rr + rX + rU) * ld, (size_t)6 * ld);
+    if (rc) return rc;
+    double *dx0 = h->hs.d, *dref = dx0 + (size_t)rx * ld, *dX = dref + (size_t)rr * ld, *dU = dX + (size_t)rX * ld;
+    std::vector<double> tmp;
+    to_soa(x0, B, rx, ld, tmp);
+    HIP_TRY(hipMemcpy(dx0, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    to_soa(ref, B, rr, ld, tmp);
+    HIP_TRY(hipMemcpy(dref, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dX, 0, (size_t)(rX + rU) * ld * sizeof(double)));
+    rc = tg_mpc12_solve_batch(h, B, ld, dx0, dref, dX, dU, h->hs.di, h->hs.di + (size_t)3 * ld, warm, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    tmp.resize((size_t)rX * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), dX, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    from_soa(tmp, B, rX, ld, X);
+    tmp.resize((size_t)rU * ld);
+    HIP_TRY(hipMemcpy(tmp.data(), dU, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    from_soa(tmp, B, rU, ld, U);
+    std::vector<int> ti((size_t)6 * ld);
+    HIP_TRY(hipMemcpy(ti.data(), h->hs.di, ti.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; b++)
+        for (int k = 0; k < 3; k++) {
+            if (status) status[3 * b + k] = ti[(size_t)k * ld + b];
+            if (iters) iters[3 * b + k] = ti[(size_t)(3 + k) * ld + b];
+        }
+    return TG_OK;
+}
+
+int tg_mpc12_intermediates(tg_mpc12 *h, const double **d_xy_max, const double **d_mixed_max,
+                           const double **d_yaw_ref, int *ld)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (!h->d_inter) return fail(TG_E_STATE, "no solve has run on this handle yet");
+    if (d_xy_max) *d_xy_max = h->xy_max();
+    if (d_mixed_max) *d_mixed_max = h->mixed_max();
+    if (d_yaw_ref) *d_yaw_ref = h->yaw_ref();
+    if (ld) *ld = h->inter_ld;
+    return TG_OK;
+}
+
+int tg_mpc12_assemble_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0, const double *d_ref,
+                            const double *d_X, double *d_q, double *d_l, double *d_u, void *stream)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
+    if (B == 0) return TG_OK;
+    if (stage < TG_FAM_XY || stage > TG_FAM_YAW) return fail(TG_E_ARG, "stage must be XY, Z or YAW");
+    if (!d_x0 || !d_ref) return fail(TG_E_ARG, "null device array");
+    if ((d_l == nullptr) != (d_u == nullptr)) return fail(TG_E_ARG, "l and u go together");
+    if (stage != TG_FAM_Z && !d_X) return fail(TG_E_ARG, "XY / Yaw assembly needs the upstream solution in X");
+    HIP_TRY(hipSetDevice(h->device));
+    if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
+    int rc = h->ensure_inter(ld);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const tg_mpc12_params &p = h->p;
+    BatchArgs a{};
+    a.B = B; a.ld = ld; a.ref_ld = ld; a.ov_ld = h->inter_ld; a.x0 = d_x0; a.ref = d_ref;
+    if (stage == TG_FAM_XY) {
+        HIP_TRY(launch_xy_bounds(B, ld, p.N, p.xy_max_vel, p.xy_max_accel, p.z_max_accel, d_X, h->xy_max(),
+                                 h->mixed_max(), s));
+        a.ov_box = h->xy_max(); a.ov_mixed = h->mixed_max();
+    } else if (stage == TG_FAM_YAW) {
+        HIP_TRY(launch_yaw_ref(B, ld, p.N, d_ref, d_X, h->yaw_ref(), s));
+        a.ref = h->yaw_ref(); a.ref_ld = h->inter_ld;
+    }
+    HIP_TRY(launch_assemble(h->st[stage].adev, a, d_q, d_l, d_u, s));
+    return TG_OK;
+}
+
+int tg_mpc12_reset_warm(tg_mpc12 *h)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    for (int f = 1; f <= 3; f++) h->st[f].warm_valid = false;
+    return TG_OK;
+}
+int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m)
+{
+    if (!h || stage < 1 || stage > 3) return fail(TG_E_ARG, "bad argument");
+    if (n) *n = h->st[stage].sp.n;
+    if (m) *m = h->st[stage].sp.m;
+    return TG_OK;
+}
+int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out)
+{
+    if (!h || !out || stage < 1 || stage > 3) return fail(TG_E_ARG, "bad argument");
+    return h->st[stage].get(which, out);
+}
+double tg_mpc12_rho(const tg_mpc12 *h, int stage) { return (h && stage >= 1 && stage <= 3) ? h->st[stage].sp.rho : 0.0; }
+
+} // extern "C"

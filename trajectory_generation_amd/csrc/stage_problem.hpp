@@ -1,0 +1,356 @@
+// Host-side construction of one horizon QP "stage" (6-DOF, or the XY / Z / Yaw stage of
+// the 12-state model) and of everything the device kernels need that is shared by all
+// instances of a batch: the reduced-KKT inverse, the stencil tables of A, A' and P in the
+// kernel's internal ordering, bound / rho templates and the I/O index maps.
+//
+// Reference for the QP itself: src/mpc_6dof.cpp:243-519 (class MPC) and
+// src/mpc_12state.cpp:74-1014 (class MPC12STATE).  Variable order of the reference:
+//   [x(0); ...; x(N); u(0); ...; u(N-1)]
+// row order: [dynamics nx(N+1) | state box nx(N+1) | input box nu*N | (XY) mixed 6N].
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/tg_mpc.h"
+#include "device_types.h"
+
+namespace tg {
+
+constexpr double kRhoMin = 1e-6;          // OSQP: step size of rows with both bounds infinite
+constexpr double kRhoEqFactor = 1e3;      // OSQP: equality rows get 1e3 * rho
+constexpr double kRhoTol = 1e-4;          // OSQP: u - l below this => equality row
+constexpr double kInfThresh = 1e30 * 1e-4; // OSQP: |bound| beyond INFTY*MIN_SCALING is infinite
+constexpr int kTile = 16;                 // instances per workgroup = MFMA column count
+
+struct StageModel {
+    int family = TG_FAM_6DOF;
+    int N = 0, nx = 0, nu = 0, n_mixed = 0;
+    double Ad[36] = {0}, Bd[18] = {0};     // row-major nx x nx, nx x nu
+    double qdiag[6] = {0};                 // diagonal of Q (the reference only sets diagonal entries)
+    double r = 0;                          // R = r * I
+    bool smoothing = false;
+    double smooth_w = 0;
+    double xmax[6] = {0}, xmin[6] = {0};   // state box (all steps, step 0 included)
+    double umax[3] = {0}, umin[3] = {0};
+    double mixed_max[6] = {0};             // XY mixed rows, symmetric
+    // where the stage reads x0 / ref and writes X / U in the model-level arrays
+    int x0_row[6] = {0};                   // row of component a in the x0 array
+    int ref_stride = 0, ref_off = 0;       // ref row of (step i, comp a) = i*ref_stride + ref_off + a
+    bool ref_pos_only = false;             // yaw: ref array is [N+1] holding only the angle
+    int X_stride = 0, X_off = 0;           // X row of (step i, comp a) = i*X_stride + X_off + a
+    int U_stride = 0, U_off = 0;
+};
+
+struct StageProblem {
+    StageModel mdl;
+    int n = 0, m = 0, Nx = 0, Nu = 0;
+    double rho = 0, sigma = 0;
+    // reference-ordered data (getters, assembly kernel)
+    std::vector<double> P, A;              // dense row-major n x n, m x n
+    std::vector<double> l_t, u_t, rho_vec; // m
+    std::vector<double> Kinv;              // dense n x n, reference order
+    // internal (kernel) ordering: axis-major, step-major cells of D states + 1 input
+    int D = 0, nax = 0, nblk = 0, nb = 0, nops = 0, n_int = 0;
+    int axis_base[kMaxAxes] = {0, 0, 0};
+    std::vector<int> op_of_block;
+    std::vector<int> var_ref;              // n_int -> reference variable or -1
+    std::vector<double> Mfrag;             // [nops][nb/16][nb/4][64]
+    double rho_eq = 0;
+    double rho_box[kMaxAxes][kMaxSlots] = {}, lb[kMaxAxes][kMaxSlots] = {}, ub[kMaxAxes][kMaxSlots] = {};
+    double rho_mx[6] = {0}, ub_mx[6] = {0};
+    // reference-order tables for the assembly kernel
+    std::vector<double> q_w;               // n
+    std::vector<int32_t> q_ref_row;        // n
+    std::vector<int32_t> asm_x0_row, asm_ov_box, asm_ov_mixed; // m
+};
+
+inline double default_rho(const StageModel &mdl)
+{
+    // Fixed step size used in place of OSQP's adaptive rho on the equilibrated problem.
+    // Geometric mean of the largest state weight and the input weight, rounded to
+    // 1-2-5; 7000/500 -> 2000, 5000/200 -> 1000, 1000/10 -> 100.
+    double w = 0;
+    for (int a = 0; a < mdl.nx; a++) w = std::max(w, mdl.qdiag[a]);
+    double g = std::sqrt(std::max(w, 1e-12) * std::max(mdl.r, 1e-12));
+    if (!(g > 0)) return 1.0;
+    double e = std::pow(10.0, std::floor(std::log10(g)));
+    double f = g / e;
+    double s = f < 1.5 ? 1 : f < 3.5 ? 2 : f < 7.5 ? 5 : 10;
+    return std::min(std::max(s * e, 1e-3), 1e6 / kRhoEqFactor);
+}
+
+// dense symmetric positive definite inverse via Cholesky, long double accumulation
+inline bool spd_inverse(const std::vector<double> &K, int n, std::vector<double> &Kinv)
+{
+    std::vector<long double> L((size_t)n * n, 0.0L);
+    for (int j = 0; j < n; j++) {
+        long double d = K[(size_t)j * n + j];
+        for (int k = 0; k < j; k++) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+        if (!(d > 0)) return false;
+        d = sqrtl(d);
+        L[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; i++) {
+            long double s = K[(size_t)i * n + j];
+            for (int k = 0; k < j; k++) s -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+            L[(size_t)i * n + j] = s / d;
+        }
+    }
+    // Linv (lower), then Kinv = Linv' * Linv
+    std::vector<long double> Li((size_t)n * n, 0.0L);
+    for (int c = 0; c < n; c++) {
+        Li[(size_t)c * n + c] = 1.0L / L[(size_t)c * n + c];
+        for (int i = c + 1; i < n; i++) {
+            long double s = 0;
+            for (int k = c; k < i; k++) s -= L[(size_t)i * n + k] * Li[(size_t)k * n + c];
+            Li[(size_t)i * n + c] = s / L[(size_t)i * n + i];
+        }
+    }
+    Kinv.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            long double s = 0;
+            for (int k = i; k < n; k++) s += Li[(size_t)k * n + i] * Li[(size_t)k * n + j];
+            Kinv[(size_t)i * n + j] = Kinv[(size_t)j * n + i] = (double)s;
+        }
+    return true;
+}
+
+inline bool build_stage(const StageModel &mdl, double rho, double sigma, StageProblem &sp,
+                        std::string &err)
+{
+    sp = StageProblem();
+    sp.mdl = mdl;
+    const int N = mdl.N, nx = mdl.nx, nu = mdl.nu;
+    const int Nx = nx * (N + 1), Nu = nu * N, n = Nx + Nu, m = 2 * Nx + Nu + mdl.n_mixed * N;
+    sp.n = n; sp.m = m; sp.Nx = Nx; sp.Nu = Nu;
+    sp.rho = rho > 0 ? rho : default_rho(mdl);
+    sp.rho = std::min(std::max(sp.rho, kRhoMin), 1e6);
+    sp.sigma = sigma;
+    // ---- P (castMPCToQPHessian) and A (castMPCToQPConstraintMatrix), dense like the reference
+    sp.P.assign((size_t)n * n, 0.0);
+    sp.A.assign((size_t)m * n, 0.0);
+    auto Pm = [&](int i, int j) -> double & { return sp.P[(size_t)i * n + j]; };
+    auto Am = [&](int i, int j) -> double & { return sp.A[(size_t)i * n + j]; };
+    for (int i = 0; i <= N; i++)
+        for (int a = 0; a < nx; a++) Pm(nx * i + a, nx * i + a) = mdl.qdiag[a];
+    for (int i = 0; i < N; i++)
+        for (int a = 0; a < nu; a++) Pm(Nx + nu * i + a, Nx + nu * i + a) = mdl.r;
+    if (mdl.smoothing)
+        for (int i = 0; i + 1 < N; i++)
+            for (int a = 0; a < nu; a++) {
+                int r0 = Nx + nu * i + a, r1 = r0 + nu;
+                Pm(r0, r0) += mdl.smooth_w; Pm(r1, r1) += mdl.smooth_w;
+                Pm(r0, r1) -= mdl.smooth_w; Pm(r1, r0) -= mdl.smooth_w;
+            }
+    for (int r = 0; r < Nx; r++) Am(r, r) = -1.0;
+    for (int i = 1; i <= N; i++)
+        for (int a = 0; a < nx; a++) {
+            for (int b = 0; b < nx; b++) Am(nx * i + a, nx * (i - 1) + b) = mdl.Ad[a * nx + b];
+            for (int b = 0; b < nu; b++) Am(nx * i + a, Nx + nu * (i - 1) + b) = mdl.Bd[a * nu + b];
+        }
+    for (int r = 0; r < n; r++) Am(Nx + r, r) = 1.0;
+    if (mdl.n_mixed) {
+        const double s3 = std::sqrt(3.0) / 2.0, s2 = std::sqrt(2.0) / 2.0;
+        for (int i = 0; i < N; i++) {
+            int r = 2 * Nx + Nu + 6 * i, c = nx * (i + 1);
+            Am(r + 0, c + 1) = s3;   Am(r + 0, c + 4) = 0.5;
+            Am(r + 1, c + 1) = s3;   Am(r + 1, c + 4) = -0.5;
+            Am(r + 2, c + 1) = 0.5;  Am(r + 2, c + 4) = s3;
+            Am(r + 3, c + 1) = -0.5; Am(r + 3, c + 4) = s3;
+            Am(r + 4, c + 2) = s2;   Am(r + 4, c + 5) = s2;
+            Am(r + 5, c + 2) = s2;   Am(r + 5, c + 5) = -s2;
+        }
+    }
+    // ---- bound templates (x0 = 0) and per-row rho
+    sp.l_t.assign(m, 0.0); sp.u_t.assign(m, 0.0); sp.rho_vec.assign(m, 0.0);
+    for (int i = 0; i <= N; i++)
+        for (int a = 0; a < nx; a++) { sp.l_t[Nx + nx * i + a] = mdl.xmin[a]; sp.u_t[Nx + nx * i + a] = mdl.xmax[a]; }
+    for (int i = 0; i < N; i++)
+        for (int a = 0; a < nu; a++) { sp.l_t[2 * Nx + nu * i + a] = mdl.umin[a]; sp.u_t[2 * Nx + nu * i + a] = mdl.umax[a]; }
+    for (int i = 0; i < N; i++)
+        for (int k = 0; k < mdl.n_mixed; k++) {
+            sp.l_t[2 * Nx + Nu + 6 * i + k] = -mdl.mixed_max[k]; sp.u_t[2 * Nx + Nu + 6 * i + k] = mdl.mixed_max[k];
+        }
+    for (int r = 0; r < m; r++) {
+        double l = sp.l_t[r], u = sp.u_t[r];
+        if (l > u) { err = "lower bound above upper bound in the constraint template"; return false; }
+        if (l < -kInfThresh && u > kInfThresh) sp.rho_vec[r] = kRhoMin;
+        else if (u - l < kRhoTol) sp.rho_vec[r] = kRhoEqFactor * sp.rho;
+        else sp.rho_vec[r] = sp.rho;
+    }
+    // ---- reduced KKT matrix K = P + sigma I + A' diag(rho) A  and its inverse
+    std::vector<double> K(sp.P);
+    for (int j = 0; j < n; j++) K[(size_t)j * n + j] += sigma;
+    {
+        std::vector<int> cols; std::vector<double> vals;
+        for (int r = 0; r < m; r++) {
+            cols.clear(); vals.clear();
+            for (int j = 0; j < n; j++) if (Am(r, j) != 0.0) { cols.push_back(j); vals.push_back(Am(r, j)); }
+            for (size_t a = 0; a < cols.size(); a++)
+                for (size_t b = 0; b < cols.size(); b++)
+                    K[(size_t)cols[a] * n + cols[b]] += sp.rho_vec[r] * vals[a] * vals[b];
+        }
+    }
+    if (!spd_inverse(K, n, sp.Kinv)) { err = "reduced KKT matrix is not positive definite"; return false; }
+    // ---- kernel ordering: (axis a, step i, slot k) -> axis_base[a] + i*(D+1) + k
+    const bool six = mdl.family == TG_FAM_6DOF, xy = mdl.family == TG_FAM_XY;
+    const int D = six ? 2 : 3, S = D + 1, nax = six ? 3 : (xy ? 2 : 1);
+    sp.D = D; sp.nax = nax;
+    sp.nblk = six ? 3 : 1;
+    const int per_axis = S * (N + 1);
+    sp.nb = ((six ? per_axis : nax * per_axis) + 15) / 16 * 16;
+    sp.n_int = sp.nblk * sp.nb;
+    for (int a = 0; a < nax; a++) sp.axis_base[a] = six ? a * sp.nb : a * per_axis;
+    sp.var_ref.assign(sp.n_int, -1);
+    std::vector<int> blk_of(n, -1);
+    for (int a = 0; a < nax; a++)
+        for (int i = 0; i <= N; i++)
+            for (int k = 0; k < S; k++) {
+                int ref;
+                if (k < D) ref = nx * i + (six ? a + 3 * k : (xy ? 3 * a + k : k));
+                else if (i < N) ref = Nx + nu * i + a;
+                else continue;
+                int ji = sp.axis_base[a] + i * S + k;
+                sp.var_ref[ji] = ref;
+                blk_of[ref] = ji / sp.nb;
+            }
+    for (int j = 0; j < n; j++) if (blk_of[j] < 0) { err = "internal: variable not mapped"; return false; }
+    // the blocks must be decoupled in K (6-DOF: the three axes never interact)
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            if (blk_of[i] != blk_of[j] && K[(size_t)i * n + j] != 0.0) { err = "internal: axes are coupled"; return false; }
+    // operators: blocks whose K sub-matrices coincide share one inverse
+    auto Kint = [&](int b, int i, int j) -> double {
+        int ri = sp.var_ref[b * sp.nb + i], rj = sp.var_ref[b * sp.nb + j];
+        return (ri >= 0 && rj >= 0) ? K[(size_t)ri * n + rj] : 0.0;
+    };
+    sp.op_of_block.assign(sp.nblk, -1);
+    std::vector<int> op_rep;
+    for (int b = 0; b < sp.nblk; b++) {
+        for (size_t o = 0; o < op_rep.size() && sp.op_of_block[b] < 0; o++) {
+            bool same = true;
+            for (int i = 0; i < sp.nb && same; i++)
+                for (int j = 0; j < sp.nb; j++) if (Kint(b, i, j) != Kint(op_rep[o], i, j)) { same = false; break; }
+            if (same) sp.op_of_block[b] = (int)o;
+        }
+        if (sp.op_of_block[b] < 0) { sp.op_of_block[b] = (int)op_rep.size(); op_rep.push_back(b); }
+    }
+    sp.nops = (int)op_rep.size();
+    // operator fragments: Mfrag[op][rb][kk][lane] = Kinv_block[rb*16 + (lane&15)][4*kk + (lane>>4)]
+    const int nrb = sp.nb / 16, ks = sp.nb / 4;
+    sp.Mfrag.assign((size_t)sp.nops * nrb * ks * 64, 0.0);
+    for (int o = 0; o < sp.nops; o++) {
+        const int b = op_rep[o];
+        for (int rb = 0; rb < nrb; rb++)
+            for (int kk = 0; kk < ks; kk++)
+                for (int lane = 0; lane < 64; lane++) {
+                    int ri = sp.var_ref[b * sp.nb + rb * 16 + (lane & 15)], rk = sp.var_ref[b * sp.nb + 4 * kk + (lane >> 4)];
+                    double v = (ri >= 0 && rk >= 0) ? sp.Kinv[(size_t)ri * n + rk] : 0.0;
+                    sp.Mfrag[(((size_t)o * nrb + rb) * ks + kk) * 64 + lane] = v;
+                }
+    }
+    // per-axis, per-slot step sizes and box templates (identical at every step)
+    sp.rho_eq = sp.rho_vec[0];
+    for (int r = 0; r < Nx; r++) if (sp.rho_vec[r] != sp.rho_eq) { err = "internal: dynamics rows must share one rho"; return false; }
+    for (int a = 0; a < nax; a++)
+        for (int k = 0; k < S; k++) {
+            int ref = sp.var_ref[sp.axis_base[a] + k];   // step 0
+            int brow = Nx + ref;
+            sp.rho_box[a][k] = sp.rho_vec[brow]; sp.lb[a][k] = sp.l_t[brow]; sp.ub[a][k] = sp.u_t[brow];
+        }
+    for (int k = 0; k < mdl.n_mixed; k++) { sp.rho_mx[k] = sp.rho_vec[2 * Nx + Nu + k]; sp.ub_mx[k] = sp.u_t[2 * Nx + Nu + k]; }
+    // ---- reference-order tables for the assembly kernel
+    sp.q_w.assign(n, 0.0); sp.q_ref_row.assign(n, -1);
+    sp.asm_x0_row.assign(m, -1); sp.asm_ov_box.assign(m, -1); sp.asm_ov_mixed.assign(m, -1);
+    for (int j = 0; j < Nx; j++) {
+        int i = j / nx, a = j % nx;
+        if (mdl.qdiag[a] != 0.0 && (!mdl.ref_pos_only || a == 0)) {
+            sp.q_w[j] = -1.0 * mdl.qdiag[a];
+            sp.q_ref_row[j] = mdl.ref_pos_only ? i : i * mdl.ref_stride + mdl.ref_off + a;
+        }
+        if (xy && i >= 1) sp.asm_ov_box[Nx + j] = nx * (i - 1) + a;
+    }
+    for (int r = 0; r < nx; r++) sp.asm_x0_row[r] = mdl.x0_row[r];
+    for (int r = 2 * Nx + Nu; r < m; r++) sp.asm_ov_mixed[r] = r - (2 * Nx + Nu);
+    return true;
+}
+
+// ---------------------------------------------------------------- model factories
+inline StageModel model_6dof(const tg_mpc6_params &p)
+{
+    // setTransitionMatrix mpc_6dof.cpp:274, setInputMatrix :287, setQ :244, setR :260,
+    // setStateBounds :299, setControlBounds :320
+    StageModel s;
+    s.family = TG_FAM_6DOF; s.N = p.N; s.nx = 6; s.nu = 3; s.n_mixed = 0;
+    for (int i = 0; i < 6; i++) s.Ad[i * 6 + i] = 1.0;
+    for (int i = 0; i < 3; i++) {
+        s.Ad[i * 6 + 3 + i] = p.dt;
+        s.Bd[(3 + i) * 3 + i] = p.dt;
+        s.qdiag[i] = p.state_weight;
+        s.xmin[3 + i] = -1.0 * p.max_vel[i]; s.xmax[3 + i] = p.max_vel[i];
+        s.umin[i] = -1.0 * p.max_accel[i];   s.umax[i] = p.max_accel[i];
+    }
+    s.r = p.input_weight;
+    s.smoothing = p.enable_control_smoothing != 0; s.smooth_w = p.smooth_input_weight;
+    s.xmin[0] = s.xmin[1] = -TG_INFTY; s.xmax[0] = s.xmax[1] = s.xmax[2] = TG_INFTY;
+    s.xmin[2] = p.min_altitude;
+    for (int a = 0; a < 6; a++) s.x0_row[a] = a;
+    s.ref_stride = 6; s.ref_off = 0; s.X_stride = 6; s.X_off = 0; s.U_stride = 3; s.U_off = 0;
+    return s;
+}
+
+inline StageModel model_12(const tg_mpc12_params &p, int family)
+{
+    // mpc_12state.cpp:75-310 (Q, R, A, B, bounds per stage), :600-630 (mixed rows)
+    StageModel s;
+    s.family = family; s.N = p.N;
+    const double dt = p.dt;
+    const double A3[9] = {1, dt, dt * dt / 2.0, 0, 1, dt, 0, 0, 1};
+    s.smoothing = p.enable_control_smoothing != 0;
+    if (family == TG_FAM_XY) {
+        s.nx = 6; s.nu = 2; s.n_mixed = 6;
+        for (int b = 0; b < 2; b++)
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) s.Ad[(3 * b + i) * 6 + 3 * b + j] = A3[i * 3 + j];
+        s.Bd[2 * 2 + 0] = dt; s.Bd[5 * 2 + 1] = dt;
+        s.qdiag[0] = s.qdiag[3] = p.xy_state_weight;
+        s.r = p.xy_input_weight; s.smooth_w = p.xy_smooth_input_weight;
+        const double b0[6] = {TG_INFTY, p.xy_max_vel, p.xy_max_accel, TG_INFTY, p.xy_max_vel, p.xy_max_accel};
+        for (int a = 0; a < 6; a++) { s.xmax[a] = b0[a]; s.xmin[a] = -b0[a]; }
+        for (int a = 0; a < 2; a++) { s.umax[a] = p.xy_max_jerk; s.umin[a] = -1.0 * p.xy_max_jerk; }
+        for (int k = 0; k < 4; k++) s.mixed_max[k] = p.xy_max_vel;
+        s.mixed_max[4] = s.mixed_max[5] = p.xy_max_accel;
+        for (int a = 0; a < 6; a++) s.x0_row[a] = a;
+        s.ref_stride = 12; s.ref_off = 0; s.X_stride = 12; s.X_off = 0; s.U_stride = 4; s.U_off = 0;
+    } else {
+        const bool z = family == TG_FAM_Z;
+        s.nx = 3; s.nu = 1; s.n_mixed = 0;
+        std::memcpy(s.Ad, A3, sizeof(A3));
+        s.Bd[2] = dt;
+        s.qdiag[0] = z ? p.z_state_weight : p.yaw_state_weight;
+        s.r = z ? p.z_input_weight : p.yaw_input_weight;
+        s.smooth_w = z ? p.z_smooth_input_weight : p.yaw_smooth_input_weight;
+        const double pmax = z ? TG_INFTY : 2.0 * M_PI;
+        const double vmax = z ? p.z_max_vel : p.yaw_max_vel;
+        const double amax = z ? p.z_max_accel : p.yaw_max_accel;
+        const double jmax = z ? p.z_max_jerk : p.yaw_max_jerk;
+        s.xmax[0] = pmax; s.xmax[1] = vmax; s.xmax[2] = amax;
+        for (int a = 0; a < 3; a++) s.xmin[a] = -s.xmax[a];
+        s.umax[0] = jmax; s.umin[0] = -1.0 * jmax;
+        const int off = z ? 6 : 9;
+        for (int a = 0; a < 3; a++) s.x0_row[a] = off + a;
+        s.ref_stride = 12; s.ref_off = off; s.X_stride = 12; s.X_off = off;
+        s.U_stride = 4; s.U_off = z ? 2 : 3;
+        s.ref_pos_only = !z;   // yaw reference comes from computeYawRefTrajectory as [N+1]
+        if (!z) { s.ref_stride = 1; s.ref_off = 0; }
+    }
+    return s;
+}
+
+} // namespace tg
