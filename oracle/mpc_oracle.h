@@ -147,6 +147,9 @@ void mpc6_cold_start(mpc6_oracle *o);
 
 typedef struct mpc12_oracle mpc12_oracle;
 mpc12_oracle *mpc12_create(const mpc12_params *p, const osqp_settings *s);
+/* per-stage solver settings (the engine picks one fixed rho per stage) */
+mpc12_oracle *mpc12_create3(const mpc12_params *p, const osqp_settings *s_xy,
+                            const osqp_settings *s_z, const osqp_settings *s_yaw);
 void mpc12_destroy(mpc12_oracle *o);
 /* one MPC12STATE::mpcLoop (mpc_12state.cpp:1374-1453).  iters/status: [z, xy, yaw].
  * inter (optional, may be NULL) receives the intermediates
@@ -159,6 +162,10 @@ int mpc6_batch(const mpc6_params *p, const osqp_settings *s, int B, const double
                const double *ref /*B x 6(N+1)*/, double *X, double *U, int *iters, int *status);
 int mpc12_batch(const mpc12_params *p, const osqp_settings *s, int B, const double *x12,
                 const double *ref12, double *X, double *U, int *iters, int *status);
+
+int mpc12_batch3(const mpc12_params *p, const osqp_settings *s_xy, const osqp_settings *s_z,
+                 const osqp_settings *s_yaw, int B, const double *x12, const double *ref12,
+                 double *X, double *U, int *iters, int *status);
 
 /* ------------------------------------------------------------------ synthetic inputs */
 /* counter-based generator shared with the Python side (splitmix64 of seed, stream, ctr) */

@@ -414,6 +414,13 @@ struct mpc12_oracle {
 
 mpc12_oracle *mpc12_create(const mpc12_params *p, const osqp_settings *s)
 {
+    return mpc12_create3(p, s, s, s);
+}
+
+mpc12_oracle *mpc12_create3(const mpc12_params *p, const osqp_settings *s_xy,
+                            const osqp_settings *s_z, const osqp_settings *s_yaw)
+{
+    const osqp_settings *ss[4] = {NULL, s_xy, s_z, s_yaw};
     mpc12_oracle *o = (mpc12_oracle *)calloc(1, sizeof(*o));
     o->p = *p;
     int N = p->N;
@@ -426,7 +433,7 @@ mpc12_oracle *mpc12_create(const mpc12_params *p, const osqp_settings *s)
         o->u[f] = (double *)calloc(o->m[f], sizeof(double));
         o->sol[f] = (double *)calloc(o->n[f], sizeof(double));
         qp12_build(p, f, P, A, o->q[f], o->l[f], o->u[f]);
-        o->w[f] = osqp_setup(o->n[f], o->m[f], P, A, o->q[f], o->l[f], o->u[f], s);
+        o->w[f] = osqp_setup(o->n[f], o->m[f], P, A, o->q[f], o->l[f], o->u[f], ss[f]);
         free(P); free(A);
         if (!o->w[f]) { mpc12_destroy(o); return NULL; }
     }
@@ -503,7 +510,15 @@ done:
 int mpc12_batch(const mpc12_params *p, const osqp_settings *s, int B, const double *x12,
                 const double *ref12, double *X, double *U, int *iters, int *status)
 {
-    mpc12_oracle *o = mpc12_create(p, s);
+    return mpc12_batch3(p, s, s, s, B, x12, ref12, X, U, iters, status);
+}
+
+int mpc12_batch3(const mpc12_params *p, const osqp_settings *s_xy, const osqp_settings *s_z,
+                 const osqp_settings *s_yaw, int B, const double *x12, const double *ref12,
+                 double *X, double *U, int *iters, int *status)
+{
+    const osqp_settings *s = s_xy;
+    mpc12_oracle *o = mpc12_create3(p, s_xy, s_z, s_yaw);
     if (!o) return -1;
     int N = p->N, ok = 0;
     for (int b = 0; b < B; b++) {

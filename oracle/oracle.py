@@ -119,6 +119,9 @@ def lib():
                                  _dp, _dp, _ip, _ip]
         L.mpc12_batch.argtypes = [C.POINTER(Mpc12Params), C.POINTER(Settings), C.c_int, _dp, _dp,
                                   _dp, _dp, _ip, _ip]
+        L.mpc12_create3.restype = C.c_void_p
+        L.mpc12_create3.argtypes = [C.POINTER(Mpc12Params)] + [C.POINTER(Settings)] * 3
+        L.mpc12_batch3.argtypes = [C.POINTER(Mpc12Params)] + [C.POINTER(Settings)] * 3 + [C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]
         L.synth_uniform.restype = C.c_double
         L.synth_uniform.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]
         L.synth_mpc6.argtypes = [C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp]
@@ -307,13 +310,21 @@ def mpc6_batch(params, settings, x0, ref):
     return dict(X=X, U=U, iters=it, status=st, n_ok=ok)
 
 
+def _three(settings):
+    """settings: one Settings for all stages, or dict(xy=, z=, yaw=)."""
+    if isinstance(settings, dict):
+        return settings["xy"], settings["z"], settings["yaw"]
+    return settings, settings, settings
+
+
 def mpc12_batch(params, settings, x12, ref12):
+    sxy, sz, syaw = _three(settings)
     x12 = np.ascontiguousarray(x12, dtype=np.float64); ref12 = np.ascontiguousarray(ref12, dtype=np.float64)
     B, N = x12.shape[0], params.N
     X = np.zeros((B, 12 * (N + 1))); U = np.zeros((B, 4 * N))
     it = np.zeros((B, 3), dtype=np.int32); st = np.zeros((B, 3), dtype=np.int32)
-    ok = lib().mpc12_batch(C.byref(params), C.byref(settings), B, _p(x12), _p(ref12), _p(X), _p(U),
-                           _pi(it), _pi(st))
+    ok = lib().mpc12_batch3(C.byref(params), C.byref(sxy), C.byref(sz), C.byref(syaw), B, _p(x12),
+                            _p(ref12), _p(X), _p(U), _pi(it), _pi(st))
     return dict(X=X, U=U, iters=it, status=st, n_ok=ok)
 
 
@@ -343,7 +354,8 @@ class Mpc6:
 class Mpc12:
     def __init__(self, params, settings):
         self.params = params
-        self._h = lib().mpc12_create(C.byref(params), C.byref(settings))
+        sxy, sz, syaw = _three(settings)
+        self._h = lib().mpc12_create3(C.byref(params), C.byref(sxy), C.byref(sz), C.byref(syaw))
         if not self._h:
             raise RuntimeError("mpc12_create failed")
 

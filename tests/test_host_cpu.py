@@ -1,0 +1,126 @@
+"""CPU tests of the host side: the C ABI library loads and exports every declared symbol, the
+facade classes keep the reference's setter / guard behaviour, the synthetic generators agree
+between Python and C, and batch sharding over ranks (gloo, world size 2) covers the batch."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from trajectory_generation_amd import _capi as capi
+    hdr = open(os.path.join(ROOT, "include", "tg_mpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes found"
+    assert declared == set(capi.SYMBOLS), (declared ^ set(capi.SYMBOLS))
+    lib = capi.load()          # raises if the library or a symbol is missing
+    for name in declared:
+        assert getattr(lib, name) is not None
+    # options default to the reference's effective OSQP settings
+    import ctypes as C
+    o = capi.SolverOpts()
+    lib.tg_default_opts(C.byref(o))
+    got = (o.sigma, o.alpha, o.eps_abs, o.eps_rel, o.max_iter, o.check_termination)
+    assert got == (1e-6, 1.6, 1e-3, 1e-3, 4000, 25)
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    import ctypes as C
+    from trajectory_generation_amd import _capi as capi
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.tg_mpc6_create(None, None, 0, C.byref(h)) == capi.TG_E_ARG
+    p = capi.Mpc6Params()
+    p.N, p.dt = 0, 0.1
+    assert lib.tg_mpc6_create(C.byref(p), None, 0, C.byref(h)) == capi.TG_E_ARG
+    assert b"N must be" in lib.tg_last_error()
+    assert lib.tg_mpc6_solve_batch(None, 1, 1, None, None, None, None, None, None, 0, None) == capi.TG_E_ARG
+
+
+def test_facade_setters_follow_the_reference(capsys):
+    from trajectory_generation_amd.mpc_6dof import MPC
+    from trajectory_generation_amd.mpc_12state import MPC12STATE
+    m = MPC()
+    assert m.setDt(0.1) and not m.setDt(-1.0) and m._dt == 0.1            # mpc_6dof.cpp:61-75
+    assert m.setMPCWindow(20) and not m.setMPCWindow(0) and m._mpcWindow == 10   # :85-100
+    assert m.setStateWeight(7.0) and not m.setStateWeight(-1.0) and m._state_weight == 7.0
+    assert not m.setMaxVel([1.0, 2.0]) and m.setMaxVel([1.0, 2.0, 3.0])
+    assert not m.setCurrentState(np.zeros(5)) and m.setCurrentState(np.zeros(6))
+    assert not m.setReferenceTraj(np.zeros(3))
+    assert not m.mpcLoop()                                                 # not initialised
+    assert m._enable_control_smoothing and m._smooth_input_weight == 10.0  # ctor defaults :48-49
+    g = MPC12STATE()
+    assert not g.setXYMaxVel(-1.0) and g._xy_MaxVel == 10.0                # :1817-1828
+    assert not g.setYawMaxAccel(-1.0) and g._yaw_MaxAccel == 100.0         # :1883-1893
+    assert not g.setZMaxJerk(-2.0) and g._z_MaxJerk == 5.0
+    assert g.setXYStateWeight(3.0) and not g.setZInputWeight(-1.0)
+    assert not g.mpcLoop() and not g.initMPCProblem()                      # limits missing
+    assert "[ERROR]" in capsys.readouterr().out
+
+
+def test_synthetic_generators_agree_with_c(oracle):
+    from trajectory_generation_amd import synth
+    for seed, N, B, first in ((0x4D5043 + 2, 20, 33, 0), (5, 7, 4, 1000)):
+        a = synth.mpc6(seed, N, 0.1, B, first); b = oracle.synth_mpc6(seed, N, 0.1, B, first)
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+        a = synth.mpc12(seed, N, 0.1, B, first); b = oracle.synth_mpc12(seed, N, 0.1, B, first)
+        np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1])
+    # the step-0 state is inside its own box and above the floor, so every instance is feasible
+    x0, _ = synth.mpc6(1, 5, 0.1, 1000)
+    assert (np.abs(x0[:, 3:]) <= 3).all() and (x0[:, 2] >= 5).all()
+
+
+def test_shard_covers_batch():
+    from trajectory_generation_amd import synth
+    for B, world in ((262144, 8), (10, 3), (5, 8), (0, 2)):
+        parts = [synth.shard(B, r, world) for r in range(world)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == B
+        for (f0, c0), (f1, _) in zip(parts, parts[1:]):
+            assert f0 + c0 == f1
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from trajectory_generation_amd import synth
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["PORT"],
+                        rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+B, N = 101, 5
+first, count = synth.shard(B, rank, world)
+x0, ref = synth.mpc6(9, N, 0.1, count, first)
+# what the sharded benchmark reduces: instance count, an iteration-like statistic, a max
+stats = torch.tensor([count, float(x0.sum()), 0.0], dtype=torch.float64)
+dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+mx = torch.tensor([float(np.abs(x0).max()) if count else 0.0], dtype=torch.float64)
+dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+full, _ = synth.mpc6(9, N, 0.1, B, 0)
+assert int(stats[0]) == B
+assert abs(float(stats[1]) - full.sum()) < 1e-9
+assert float(mx[0]) == np.abs(full).max()
+np.testing.assert_array_equal(x0, full[first:first + count])
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_two_rank_sharding_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    port = str(29500 + os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", PORT=port, MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for pr in procs:
+        out, _ = pr.communicate(timeout=180)
+        assert pr.returncode == 0, out.decode()

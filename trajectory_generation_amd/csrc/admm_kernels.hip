@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AsmDev P, const Bat
                                                         double *__restrict__ l,
                                                         double *__restrict__ u)
 {
+#pragma clang fp contract(off)
     const int inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= a.B) return;
     const int r0 = blockIdx.y * P.rows_per_block;
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(256) void xy_bounds_kernel(int B, int ld, int N, do
                                                          double *__restrict__ xy_max,
                                                          double *__restrict__ mixed_max)
 {
+#pragma clang fp contract(off)   // same roundings as the reference's separate multiply and subtract
     const int inst = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y + 1;
     if (inst >= B || i > N) return;
@@ -559,6 +561,7 @@ __global__ __launch_bounds__(256) void yaw_ref_kernel(int B, int ld, int N,
                                                        const double *__restrict__ X,
                                                        double *__restrict__ yaw_ref)
 {
+#pragma clang fp contract(off)
     const int inst = blockIdx.x * blockDim.x + threadIdx.x;
     const int i = blockIdx.y;
     if (inst >= B || i > N) return;
