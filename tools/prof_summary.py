@@ -1,0 +1,66 @@
+"""Turns rocprofv3 result databases (gpurun_out/<dir>/{trace,pmc_fetch,pmc_write}/*.db) into the
+text / JSON summaries committed under profiles/.
+
+  python tools/prof_summary.py gpurun_out/prof_r01 profiles/r01 mpc_6dof_B4096_N20
+"""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+
+def one_db(d):
+    f = glob.glob(os.path.join(d, "*.db"))
+    return sqlite3.connect(f[0]) if f else None
+
+
+def main(src, dst_prefix, workload):
+    out = {"workload": workload}
+    lines = []
+    db = one_db(os.path.join(src, "trace"))
+    if db:
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --no-cpu-baseline")
+        lines.append("%-90s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+        for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
+            lines.append("%-90s %8d %14.1f %12.2f %8.3f" % (name[:90], calls, total / 1e3 if total > 1e6 else total, avg / 1e3 if total > 1e6 else avg, pct))
+            if "admm_kernel" in name:
+                out["admm_kernel_avg_us"] = avg
+                out["admm_kernel_calls"] = calls
+        # register / LDS footprint of the dominant kernel
+        row = db.execute("select kernel_name, vgpr_count, accum_vgpr_count, sgpr_count, lds_block_size, scratch_size, "
+                         "grid_size, workgroup_size from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                         "on d.kernel_id = s.id where kernel_name like '%admm_kernel%' limit 1").fetchone() \
+            if False else None
+    for key, sub, cname in (("fetch_kb", "pmc_fetch", "FETCH_SIZE"), ("write_kb", "pmc_write", "WRITE_SIZE")):
+        db = one_db(os.path.join(src, sub))
+        if not db:
+            continue
+        rows = list(db.execute("select kernel_name, value, vgpr_count, accum_vgpr_count, sgpr_count, lds_block_size, "
+                               "scratch_size, grid_size, workgroup_size from counters_collection where counter_name = ? "
+                               "and kernel_name like '%admm_kernel%'", (cname,)))
+        if rows:
+            vals = [r[1] for r in rows]
+            out[key + "_per_launch_raw"] = sum(vals) / len(vals)
+            out["admm_kernel_resources"] = dict(zip(["vgpr", "agpr", "sgpr", "lds_bytes", "scratch", "grid", "wg"], rows[0][2:]))
+            lines.append("")
+            lines.append("rocprofv3 --pmc %s : admm_kernel, %d launches, mean %.1f KB per launch (raw counter)" %
+                         (cname, len(vals), sum(vals) / len(vals)))
+    if "fetch_kb_per_launch_raw" in out:
+        # gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide streaming reads; the kernel's
+        # reads are 8 B / lane, for which the counter is not calibrated: both figures are kept
+        raw = out["fetch_kb_per_launch_raw"] * 1024
+        wr = out.get("write_kb_per_launch_raw", 0.0) * 1024
+        out["hbm_bytes_per_launch_raw"] = raw + wr
+        out["hbm_bytes_per_launch_fetch_x2"] = 2 * raw + wr
+        lines.append("HBM bytes per launch: raw %.0f, with the gfx950 FETCH_SIZE x2 correction %.0f" %
+                     (raw + wr, 2 * raw + wr))
+    os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
+    open(dst_prefix + "_rocprof_summary.txt", "w").write("\n".join(lines) + "\n")
+    json.dump(out, open(dst_prefix + "_rocprof_summary.json", "w"), indent=1)
+    print("\n".join(lines))
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])

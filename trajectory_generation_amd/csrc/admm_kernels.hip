@@ -51,10 +51,20 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
     return d == 0 ? 1.0 : (d == 1 ? dt : c2);
 }
 
-template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR>
+// KSREG > 0: the operator fragments of this wave's row block stay in registers for the whole
+// solve (needs MAXRBW == 1 and ks <= KSREG); KSREG == 0: they are streamed from L2.
+//
+// LDS regions, all [rows][16 instances] of doubles, addressed by absolute double index:
+//   V0  rhs of the linear solve            n_int + S rows (the last S rows take the writes of
+//   VX  xt, and x during a check           n_int + S rows  a thread's unused cell slots)
+//   WEQ w = rho z - y of the dynamics rows ncell*D + D rows
+//   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
+//   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
+template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR, int KSREG>
 __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
+    constexpr int MAXGRP = NAX == 3 ? 2 : 1;   // 6-DOF: {x, y} share an operator, z has its own
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int t = tid & 15, g = tid >> 4;
@@ -64,32 +74,42 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
 
-    // LDS carve-up (all [rows][16 instances] of doubles)
-    double *v0 = lds;                                                       // rhs
-    double *vx = P.separate_xt ? lds + (size_t)n_int * 16 : lds;            // xt (and x during checks)
-    double *weq = lds + (size_t)(P.separate_xt ? 2 : 1) * n_int * 16;       // w of dynamics rows [ncell*D]
-    double *wmx = weq + (size_t)ncell * D * 16;                             // w of mixed rows [N1*6]
-    double *ctab = wmx + (MIXED ? (size_t)N1 * 6 * 16 : 0);                 // [NAX][S][3] rho, lb, ub
-    unsigned long long *red = (unsigned long long *)(ctab + NAX * S * 3);   // [7][16]
+    const int V0 = 0;
+    const int VX = P.separate_xt ? (n_int + S) * 16 : 0;
+    const int WEQ = (P.separate_xt ? 2 : 1) * (n_int + S) * 16;
+    const int WMX = WEQ + (ncell * D + D) * 16;
+    const int ZERO = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);
+    const int CTAB = ZERO + 8 * 16;                                          // [NAX][S][3] rho, lb, ub
+    unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [7][16]
+    double *v0 = lds + V0, *vx = lds + VX;
 
     const double sigma = P.sigma, alpha = P.alpha, oma = 1.0 - P.alpha;
     const double dt = P.dt, c2 = P.c2, rho_eq = P.rho_eq;
     constexpr double s3 = 0.86602540378443864676, s2 = 0.70710678118654752440; // sqrt(3)/2, sqrt(2)/2
 
+    for (int j = tid; j < CTAB; j += 256) lds[j] = 0.0;
     if (tid < NAX * S) {
         const int ax = tid / S, k = tid % S;
-        ctab[tid * 3 + 0] = P.rho_box[ax][k];
-        ctab[tid * 3 + 1] = P.lb[ax][k];
-        ctab[tid * 3 + 2] = P.ub[ax][k];
+        lds[CTAB + tid * 3 + 0] = P.rho_box[ax][k];
+        lds[CTAB + tid * 3 + 1] = P.lb[ax][k];
+        lds[CTAB + tid * 3 + 2] = P.ub[ax][k];
     }
+    __syncthreads();
 
     // ------------------------------------------------------------ per-thread cell state
     double x[MAXC][S], zb[MAXC][S], yb[MAXC][S];   // variables and their identity box rows
-    double zg[MAXC][D], yg[MAXC][D];               // dynamics rows of the cell
+    double zg[MAXC][D], yg[MAXC][D], bg[MAXC][D];  // dynamics rows of the cell, their l = u
     double q[MAXC];                                // q of the position slot
-    double ovb[MIXED ? MAXC : 1][2];               // XY: per-instance |v|, |a| box of the cell
+    double hiv[MIXED ? MAXC : 1][2];               // XY: |v|, |a| box of the cell (per instance)
     double zm[MIXED ? MAXC : 1][6], ym[MIXED ? MAXC : 1][6], ovm[MIXED ? MAXC : 1][6];
-    int cax[MAXC], cst[MAXC];                      // axis and step of the cell (-1: none)
+    int i_var[MAXC];     // index of the cell's first variable, relative to V0 / VX
+    int i_prev[MAXC];    // absolute index of the previous cell's variables in VX (or ZERO)
+    int i_wnext[MAXC];   // absolute index of the next cell's dynamics-row w (or ZERO)
+    int i_ct[MAXC];      // absolute index of the cell's axis in the constant table
+    int i_mx[MIXED ? MAXC : 1];     // absolute index of the step's mixed-row w (or ZERO)
+    int i_oth[MIXED ? MAXC : 1];    // XY: index of the other axis' cell of the same step, rel. to VX
+    bool mixrow[MIXED ? MAXC : 1];  // this cell updates the mixed rows of its step
+    bool axis0[MIXED ? MAXC : 1];
 
     double qn = 0.0;
 #pragma unroll
@@ -97,32 +117,50 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
         const int c = g + 16 * cc;
         const bool act = c < ncell;
         const int ax = act ? c / N1 : 0;
-        const int st = act ? c - ax * N1 : -1;
-        cax[cc] = ax; cst[cc] = st;
+        const int st = act ? c - ax * N1 : 0;
+        int abase = 0, x0r = 0, refoff = 0;
+        double qw = 0.0;
+#pragma unroll
+        for (int k = 0; k < NAX; k++)
+            if (ax == k) { abase = P.axis_base[k]; x0r = P.x0_row[k]; refoff = P.ref_off[k]; qw = P.qw[k]; }
+        i_var[cc] = act ? (abase + st * S) * 16 + t : n_int * 16 + t;
+        i_prev[cc] = (act && st > 0) ? VX + i_var[cc] - S * 16 : ZERO + t;
+        i_wnext[cc] = (act && st < N) ? WEQ + ((c + 1) * D) * 16 + t : ZERO + t;
+        i_ct[cc] = CTAB + ax * S * 3;
         q[cc] = 0.0;
 #pragma unroll
         for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; yb[cc][k] = 0.0; }
 #pragma unroll
-        for (int k = 0; k < D; k++) { zg[cc][k] = 0.0; yg[cc][k] = 0.0; }
+        for (int k = 0; k < D; k++) { zg[cc][k] = 0.0; yg[cc][k] = 0.0; bg[cc][k] = 0.0; }
         if (MIXED) {
-            ovb[cc][0] = ovb[cc][1] = 0.0;
+            const int oth = ax == 0 ? P.axis_base[1] : P.axis_base[0];
+            i_oth[cc] = act ? (oth + st * S) * 16 + t : n_int * 16 + t;
+            i_mx[cc] = (act && st >= 1) ? WMX + st * 6 * 16 + t : ZERO + t;
+            mixrow[cc] = act && ax == 0 && st >= 1;
+            axis0[cc] = ax == 0;
+            hiv[cc][0] = lds[i_ct[cc] + 1 * 3 + 2];
+            hiv[cc][1] = lds[i_ct[cc] + 2 * 3 + 2];
 #pragma unroll
             for (int k = 0; k < 6; k++) { zm[cc][k] = 0.0; ym[cc][k] = 0.0; ovm[cc][k] = 0.0; }
         }
         if (act && valid) {
-            q[cc] = P.qw[ax] * a.ref[(size_t)(st * P.ref_stride + P.ref_off[ax]) * a.ref_ld + inst];
+            q[cc] = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
             qn = fmax(qn, fabs(q[cc]));
+            if (st == 0) {
+#pragma unroll
+                for (int k = 0; k < D; k++) bg[cc][k] = -a.x0[(size_t)(x0r + k * P.x0_slot) * a.ld + inst];
+            }
             if (MIXED && st >= 1) {
                 const size_t r0 = (size_t)(6 * (st - 1) + 3 * ax) * a.ov_ld + inst;
-                ovb[cc][0] = a.ov_box[r0 + (size_t)a.ov_ld];
-                ovb[cc][1] = a.ov_box[r0 + (size_t)2 * a.ov_ld];
+                hiv[cc][0] = a.ov_box[r0 + (size_t)a.ov_ld];
+                hiv[cc][1] = a.ov_box[r0 + (size_t)2 * a.ov_ld];
                 if (ax == 0) {
 #pragma unroll
                     for (int k = 0; k < 6; k++) ovm[cc][k] = a.ov_mixed[(size_t)(6 * (st - 1) + k) * a.ov_ld + inst];
                 }
             }
             if (a.warm_in) {
-                const size_t w0 = (size_t)(P.axis_base[ax] + st * S) * a.ldw + inst;
+                const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
 #pragma unroll
                 for (int k = 0; k < S; k++) {
                     x[cc][k] = a.warm[w0 + (size_t)k * a.ldw];
@@ -145,24 +183,34 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                 }
             }
         }
-        if (act) {
+        // w of the cell's rows for the first rhs (unused slots write the spare rows at the end)
+        const int cw = act ? c : ncell;
 #pragma unroll
-            for (int k = 0; k < D; k++) weq[(c * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
-            if (MIXED && ax == 0) {
+        for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
+        if (MIXED) {
+            if (mixrow[cc]) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
+                for (int k = 0; k < 6; k++) lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
             }
         }
     }
-    // zero the padding rows of the rhs vector once (they multiply zero operator columns,
-    // but must not hold NaN bit patterns)
-    for (int j = tid; j < n_int * 16; j += 256) v0[j] = 0.0;
     if (g == 0) red[6 * 16 + t] = 0ull;
     __syncthreads();
     qn = wave_gmax(qn);
     if ((lane >> 4) == 0) lds_max(&red[6 * 16 + t], qn);
     __syncthreads();
     qn = __longlong_as_double((long long)red[6 * 16 + t]);
+
+    double mreg[KSREG > 0 ? MAXGRP : 1][KSREG > 0 ? KSREG : 1];
+    if constexpr (KSREG > 0) {
+#pragma unroll
+        for (int grp = 0; grp < MAXGRP; grp++)
+#pragma unroll
+            for (int kk = 0; kk < KSREG; kk++) {
+                const bool in = grp < P.ngrp && kk < ks && wave < nrb;
+                mreg[grp][kk] = in ? P.Mfrag[((size_t)P.grp_op[grp] * nrb * ks + (size_t)wave * ks + kk) * 64 + lane] : 0.0;
+            }
+    }
 
     bool done = !valid;
     const int max_iter = P.max_iter, check = P.check;
@@ -171,78 +219,114 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
-            const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
-            if (st >= 0) {
-                double wn[D], wo[D];
+            const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+            double wn[D], wo[D];
 #pragma unroll
-                for (int k = 0; k < D; k++) {
-                    wo[k] = rho_eq * (zg[cc][k] - yg[cc][k]);
-                    wn[k] = st < N ? weq[((c + 1) * D + k) * 16 + t] : 0.0;
-                }
-                const double *ct = ctab + ax * S * 3;
-                double *out = v0 + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
-                double mixc[3] = {0.0, 0.0, 0.0};
-                if (MIXED && st >= 1) {
-                    const double *wm = wmx + (size_t)st * 6 * 16 + t;
-                    const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                    if (ax == 0) { mixc[1] = s3 * (w0 + w1) + 0.5 * (w2 - w3); mixc[2] = s2 * (w4 + w5); }
-                    else         { mixc[1] = 0.5 * (w0 - w1) + s3 * (w2 + w3); mixc[2] = s2 * (w4 - w5); }
-                }
-#pragma unroll
-                for (int l = 0; l < D; l++) {
-                    double acc = sigma * x[cc][l] + ct[l * 3] * (zb[cc][l] - yb[cc][l]) - wo[l];
-                    if (l == 0) acc -= q[cc];
-#pragma unroll
-                    for (int k = 0; k <= l; k++) acc += chain_coef<D>(k, l, dt, c2) * wn[k];
-                    if (MIXED && l >= 1) acc += mixc[l];
-                    out[l * 16] = acc;
-                }
-                // input slot (absent at step N: the padding variable stays zero)
-                out[D * 16] = st < N ? sigma * x[cc][D] + ct[D * 3] * (zb[cc][D] - yb[cc][D]) + dt * wn[D - 1]
-                                     : 0.0;
+            for (int k = 0; k < D; k++) {
+                wo[k] = rho_eq * (zg[cc][k] - yg[cc][k]);
+                wn[k] = lds[i_wnext[cc] + k * 16];
             }
+            (void)cw;
+            double mixc[3] = {0.0, 0.0, 0.0};
+            if (MIXED) {
+                const double *wm = lds + i_mx[cc];
+                const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
+                const double ca = axis0[cc] ? s3 : 0.5, cb = axis0[cc] ? 0.5 : s3, sg = axis0[cc] ? 1.0 : -1.0;
+                mixc[1] = ca * (w0 + sg * w1) + cb * (w2 - sg * w3);
+                mixc[2] = s2 * (w4 + sg * w5);
+            }
+            double *out = v0 + i_var[cc];
+            const double *ct = lds + i_ct[cc];
+#pragma unroll
+            for (int l = 0; l < D; l++) {
+                double acc = sigma * x[cc][l] + ct[l * 3] * (zb[cc][l] - yb[cc][l]) - wo[l];
+                if (l == 0) acc -= q[cc];
+#pragma unroll
+                for (int k = 0; k <= l; k++) acc += chain_coef<D>(k, l, dt, c2) * wn[k];
+                if (MIXED && l >= 1) acc += mixc[l];
+                out[l * 16] = acc;
+            }
+            // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
+            out[D * 16] = sigma * x[cc][D] + ct[D * 3] * (zb[cc][D] - yb[cc][D]) + dt * wn[D - 1];
         }
         __syncthreads();
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
-        for (int grp = 0; grp < P.ngrp; grp++) {
-            const int b0 = P.grp_first[grp];
-            const bool two = PAIR && P.grp_cnt[grp] == 2;
-            const double *Mop = P.Mfrag + (size_t)P.grp_op[grp] * nrb * ks * 64 + lane;
-            const double *bp0 = v0 + ((size_t)b0 * nb + (lane >> 4)) * 16 + (lane & 15);
-            const double *bp1 = bp0 + (size_t)nb * 16;
-            d4 acc0[MAXRBW], acc1[PAIR ? MAXRBW : 1];
+        // D[16 rows x 16 instances] += A[16 x 4] * B[4 x 16]: A = operator fragment (registers
+        // when it fits, else streamed from L2 through a prefetch ring), B = rhs rows from LDS
 #pragma unroll
-            for (int i = 0; i < MAXRBW; i++) acc0[i] = (d4){0, 0, 0, 0};
+        for (int grp = 0; grp < MAXGRP; grp++) {
+            if (grp < P.ngrp) {
+                const int b0 = P.grp_first[grp];
+                const bool two = PAIR && P.grp_cnt[grp] == 2;
+                const double *bp0 = v0 + ((size_t)b0 * nb + (lane >> 4)) * 16 + (lane & 15);
+                const double *bp1 = bp0 + (size_t)nb * 16;
+                d4 acc0[MAXRBW], acc1[PAIR ? MAXRBW : 1];
 #pragma unroll
-            for (int i = 0; i < (PAIR ? MAXRBW : 1); i++) acc1[i] = (d4){0, 0, 0, 0};
-#pragma unroll 4
-            for (int kk = 0; kk < ks; kk++) {
-                const double bf0 = bp0[kk * 64];
-                double bf1 = 0.0;
-                if (PAIR && two) bf1 = bp1[kk * 64];
+                for (int i = 0; i < MAXRBW; i++) acc0[i] = (d4){0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < (PAIR ? MAXRBW : 1); i++) acc1[i] = (d4){0, 0, 0, 0};
+                if constexpr (KSREG > 0) {
+#pragma unroll
+                    for (int kk = 0; kk < KSREG; kk++) {
+                        if (kk < ks) {
+                            const double bf0 = bp0[kk * 64];
+                            acc0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[grp][kk], bf0, acc0[0], 0, 0, 0);
+                            if (PAIR && two) {
+                                const double bf1 = bp1[kk * 64];
+                                acc1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[grp][kk], bf1, acc1[0], 0, 0, 0);
+                            }
+                        }
+                    }
+                } else {
+                    constexpr int PD = MAXRBW <= 2 ? 8 : 4;   // k steps in flight
+                    const double *Mop = P.Mfrag + (size_t)P.grp_op[grp] * nrb * ks * 64 + lane;
+                    const double *Mrow[MAXRBW];
+                    double af[PD][MAXRBW];
+#pragma unroll
+                    for (int i = 0; i < MAXRBW; i++) {
+                        const int rb = wave + 4 * i;
+                        Mrow[i] = Mop + (size_t)(rb < nrb ? rb : nrb - 1) * ks * 64;
+                    }
+#pragma unroll
+                    for (int p = 0; p < PD; p++)
+#pragma unroll
+                        for (int i = 0; i < MAXRBW; i++) af[p][i] = Mrow[i][(size_t)(p < ks ? p : ks - 1) * 64];
+                    for (int kk = 0; kk < ks; kk += PD) {
+#pragma unroll
+                        for (int p = 0; p < PD; p++) {
+                            const int k = kk + p;
+                            if (k < ks) {
+                                const double bf0 = bp0[k * 64];
+                                double bf1 = 0.0;
+                                if (PAIR && two) bf1 = bp1[k * 64];
+                                const int kn = k + PD < ks ? k + PD : k;
+#pragma unroll
+                                for (int i = 0; i < MAXRBW; i++) {
+                                    const double a_ = af[p][i];
+                                    af[p][i] = Mrow[i][(size_t)kn * 64];
+                                    if (wave + 4 * i < nrb) {
+                                        acc0[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf0, acc0[i], 0, 0, 0);
+                                        if (PAIR && two)
+                                            acc1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf1, acc1[i], 0, 0, 0);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (!P.separate_xt) __syncthreads();
 #pragma unroll
                 for (int i = 0; i < MAXRBW; i++) {
                     const int rb = wave + 4 * i;
                     if (rb < nrb) {
-                        const double af = Mop[((size_t)rb * ks + kk) * 64];
-                        acc0[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf0, acc0[i], 0, 0, 0);
-                        if (PAIR && two)
-                            acc1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf1, acc1[i], 0, 0, 0);
-                    }
-                }
-            }
-            if (!P.separate_xt) __syncthreads();
+                        double *o0 = vx + ((size_t)b0 * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
 #pragma unroll
-            for (int i = 0; i < MAXRBW; i++) {
-                const int rb = wave + 4 * i;
-                if (rb < nrb) {
-                    double *o0 = vx + ((size_t)b0 * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
+                        for (int r = 0; r < 4; r++) o0[r * 64] = acc0[i][r];
+                        if (PAIR && two) {
+                            double *o1 = o0 + (size_t)nb * 16;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) o0[r * 64] = acc0[i][r];
-                    if (PAIR && two) {
-                        double *o1 = o0 + (size_t)nb * 16;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) o1[r * 64] = acc1[i][r];
+                            for (int r = 0; r < 4; r++) o1[r * 64] = acc1[i][r];
+                        }
                     }
                 }
             }
@@ -251,46 +335,43 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
         // -------------------------------------------------------- relaxation, projection, dual
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
-            const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
-            if (st >= 0) {
-                const double *xin = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
-                const double *ct = ctab + ax * S * 3;
-                double xt[S], xp[S];
+            const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+            const double *xin = vx + i_var[cc];
+            const double *xpr = lds + i_prev[cc];
+            const double *ct = lds + i_ct[cc];
+            double xt[S], xp[S];
 #pragma unroll
-                for (int k = 0; k < S; k++) {
-                    xt[k] = xin[k * 16];
-                    xp[k] = st > 0 ? xin[(k - S) * 16] : 0.0;
-                }
-                // variables and their box rows
+            for (int k = 0; k < S; k++) { xt[k] = xin[k * 16]; xp[k] = xpr[k * 16]; }
+            // variables and their box rows
 #pragma unroll
-                for (int k = 0; k < S; k++) {
-                    x[cc][k] = alpha * xt[k] + oma * x[cc][k];
-                    const double zr = alpha * xt[k] + oma * zb[cc][k];
-                    const double s = zr + yb[cc][k];
-                    double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
-                    if (MIXED && st >= 1 && (k == 1 || k == 2)) { hi = ovb[cc][k - 1]; lo = -hi; }
-                    const double zn = clampd(s, lo, hi);
-                    yb[cc][k] = s - zn;
-                    zb[cc][k] = zn;
-                }
-                // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
+            for (int k = 0; k < S; k++) {
+                x[cc][k] = alpha * xt[k] + oma * x[cc][k];
+                const double zr = alpha * xt[k] + oma * zb[cc][k];
+                const double s = zr + yb[cc][k];
+                double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
+                if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
+                const double zn = clampd(s, lo, hi);
+                yb[cc][k] = s - zn;
+                zb[cc][k] = zn;
+            }
+            // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
 #pragma unroll
-                for (int k = 0; k < D; k++) {
-                    double zt = -xt[k];
+            for (int k = 0; k < D; k++) {
+                double zt = -xt[k];
 #pragma unroll
-                    for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
-                    if (k == D - 1) zt += dt * xp[D];
-                    double b = 0.0;
-                    if (st == 0 && valid) b = -a.x0[(size_t)(P.x0_row[ax] + k * P.x0_slot) * a.ld + inst];
-                    const double zr = alpha * zt + oma * zg[cc][k];
-                    const double s = zr + yg[cc][k];
-                    yg[cc][k] = s - b;
-                    zg[cc][k] = b;
-                    weq[(c * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
-                }
-                if (MIXED && ax == 0 && st >= 1) {
+                for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
+                if (k == D - 1) zt += dt * xp[D];
+                const double b = bg[cc][k];
+                const double zr = alpha * zt + oma * zg[cc][k];
+                const double s = zr + yg[cc][k];
+                yg[cc][k] = s - b;
+                zg[cc][k] = b;
+                lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+            }
+            if (MIXED) {
+                if (mixrow[cc]) {
                     // mixed rows of step st (mpc_12state.cpp:600-630), second axis read from LDS
-                    const double *yin = vx + (size_t)(P.axis_base[1] + st * S) * 16 + t;
+                    const double *yin = vx + i_oth[cc];
                     const double vxx = xt[1], axx = xt[2], vyy = yin[16], ayy = yin[32];
                     const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
                                            -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
@@ -301,7 +382,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                         const double zn = clampd(s, -ovm[cc][k], ovm[cc][k]);
                         ym[cc][k] = s - zn;
                         zm[cc][k] = zn;
-                        wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * (zn - ym[cc][k]);
+                        lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zn - ym[cc][k]);
                     }
                 }
             }
@@ -313,19 +394,19 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
 #pragma unroll
                 for (int k = 0; k < 6; k++) red[k * 16 + t] = 0ull;
             }
-            // x -> vx, y of the dynamics / mixed rows -> weq / wmx (restored below)
+            // x -> VX, y of the dynamics / mixed rows -> WEQ / WMX (restored below)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
-                if (st >= 0) {
-                    double *xo = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+                const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+                double *xo = vx + i_var[cc];
 #pragma unroll
-                    for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
+                for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
 #pragma unroll
-                    for (int k = 0; k < D; k++) weq[(c * D + k) * 16 + t] = rho_eq * yg[cc][k];
-                    if (MIXED && ax == 0) {
+                for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * yg[cc][k];
+                if (MIXED) {
+                    if (mixrow[cc]) {
 #pragma unroll
-                        for (int k = 0; k < 6; k++) wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * ym[cc][k];
+                        for (int k = 0; k < 6; k++) lds[i_mx[cc] + k * 16] = P.rho_mx[k] * ym[cc][k];
                     }
                 }
             }
@@ -333,23 +414,29 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
             double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
-                if (st >= 0) {
-                    const double *xin = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
-                    const double *ct = ctab + ax * S * 3;
+                const int c = g + 16 * cc;
+                if (c < ncell) {
+                    const int ax = c / N1, st = c - ax * N1;
+                    const double *xin = vx + i_var[cc];
+                    const double *xpr = lds + i_prev[cc];
+                    const double *ct = lds + i_ct[cc];
+                    double pdiag = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NAX; k++) if (ax == k) pdiag = P.pdiag[k];
                     double yn[D], mixc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int k = 0; k < D; k++) yn[k] = st < N ? weq[((c + 1) * D + k) * 16 + t] : 0.0;
-                    if (MIXED && st >= 1) {
-                        const double *wm = wmx + (size_t)st * 6 * 16 + t;
+                    for (int k = 0; k < D; k++) yn[k] = lds[i_wnext[cc] + k * 16];
+                    if (MIXED) {
+                        const double *wm = lds + i_mx[cc];
                         const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                        if (ax == 0) { mixc[1] = s3 * (w0 + w1) + 0.5 * (w2 - w3); mixc[2] = s2 * (w4 + w5); }
-                        else         { mixc[1] = 0.5 * (w0 - w1) + s3 * (w2 + w3); mixc[2] = s2 * (w4 - w5); }
+                        const double ca = axis0[cc] ? s3 : 0.5, cb = axis0[cc] ? 0.5 : s3, sg = axis0[cc] ? 1.0 : -1.0;
+                        mixc[1] = ca * (w0 + sg * w1) + cb * (w2 - sg * w3);
+                        mixc[2] = s2 * (w4 + sg * w5);
                     }
                     // dual residual P x + q + A' y on the state slots
 #pragma unroll
                     for (int l = 0; l < D; l++) {
-                        const double px = l == 0 ? P.pdiag[ax] * x[cc][0] : 0.0;
+                        const double px = l == 0 ? pdiag * x[cc][0] : 0.0;
                         double aty = ct[l * 3] * yb[cc][l] - rho_eq * yg[cc][l];
 #pragma unroll
                         for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
@@ -362,7 +449,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                     if (st < N) { // input slot: P = r I + smooth * D'D (first difference of inputs)
                         double px = P.r * x[cc][D];
                         if (P.smooth != 0.0) {
-                            const double um = st > 0 ? xin[(D - S) * 16] : x[cc][D];
+                            const double um = st > 0 ? xpr[D * 16] : x[cc][D];
                             const double up = st < N - 1 ? xin[(D + S) * 16] : x[cc][D];
                             px += P.smooth * ((x[cc][D] - um) + (x[cc][D] - up));
                         }
@@ -384,26 +471,26 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
 #pragma unroll
                     for (int k = 0; k < D; k++) {
                         double axv = -x[cc][k];
-                        if (st > 0) {
 #pragma unroll
-                            for (int l = k; l < D; l++) axv += chain_coef<D>(k, l, dt, c2) * xin[(l - S) * 16];
-                            if (k == D - 1) axv += dt * xin[(D - S) * 16];
-                        }
+                        for (int l = k; l < D; l++) axv += chain_coef<D>(k, l, dt, c2) * xpr[l * 16];
+                        if (k == D - 1) axv += dt * xpr[D * 16];
                         m_rp = fmax(m_rp, fabs(axv - zg[cc][k]));
                         m_ax = fmax(m_ax, fabs(axv));
                         m_z = fmax(m_z, fabs(zg[cc][k]));
                     }
                     // ... mixed rows
-                    if (MIXED && ax == 0 && st >= 1) {
-                        const double *yin = vx + (size_t)(P.axis_base[1] + st * S) * 16 + t;
-                        const double vxx = x[cc][1], axx = x[cc][2], vyy = yin[16], ayy = yin[32];
-                        const double ax6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
-                                               -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+                    if (MIXED) {
+                        if (mixrow[cc]) {
+                            const double *yin = vx + i_oth[cc];
+                            const double vxx = x[cc][1], axx = x[cc][2], vyy = yin[16], ayy = yin[32];
+                            const double ax6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
+                                                   -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
 #pragma unroll
-                        for (int k = 0; k < 6; k++) {
-                            m_rp = fmax(m_rp, fabs(ax6[k] - zm[cc][k]));
-                            m_ax = fmax(m_ax, fabs(ax6[k]));
-                            m_z = fmax(m_z, fabs(zm[cc][k]));
+                            for (int k = 0; k < 6; k++) {
+                                m_rp = fmax(m_rp, fabs(ax6[k] - zm[cc][k]));
+                                m_ax = fmax(m_ax, fabs(ax6[k]));
+                                m_z = fmax(m_z, fabs(zm[cc][k]));
+                            }
                         }
                     }
                 }
@@ -446,9 +533,13 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                 if (a.warm_out) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
-                        const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
-                        if (st >= 0) {
-                            const size_t w0 = (size_t)(P.axis_base[ax] + st * S) * a.ldw + inst;
+                        const int c = g + 16 * cc;
+                        if (c < ncell) {
+                            const int ax = c / N1, st = c - ax * N1;
+                            int abase = 0;
+#pragma unroll
+                            for (int k = 0; k < NAX; k++) if (ax == k) abase = P.axis_base[k];
+                            const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
 #pragma unroll
                             for (int k = 0; k < S; k++) {
                                 a.warm[w0 + (size_t)k * a.ldw] = x[cc][k];
@@ -474,16 +565,16 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                 }
             }
             if (__syncthreads_and(done ? 1 : 0)) break;
-            // weq / wmx held y during the check: restore w = rho (z - y/rho)
+            // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int st = cst[cc], ax = cax[cc], c = g + 16 * cc;
-                if (st >= 0) {
+                const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
 #pragma unroll
-                    for (int k = 0; k < D; k++) weq[(c * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
-                    if (MIXED && ax == 0) {
+                for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
+                if (MIXED) {
+                    if (mixrow[cc]) {
 #pragma unroll
-                        for (int k = 0; k < 6; k++) wmx[(st * 6 + k) * 16 + t] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
+                        for (int k = 0; k < 6; k++) lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
                     }
                 }
             }
@@ -574,14 +665,15 @@ __global__ __launch_bounds__(256) void yaw_ref_kernel(int B, int ld, int N,
 size_t admm_lds_bytes(const StageDev &P)
 {
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
-    size_t rows = (size_t)(P.separate_xt ? 2 : 1) * P.n_int + (size_t)ncell * P.D + (P.mixed ? (size_t)(P.N + 1) * 6 : 0);
-    return rows * 16 * sizeof(double) + (size_t)P.nax * S * 3 * sizeof(double) + 7 * 16 * sizeof(double);
+    size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
+                  (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8;
+    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + 7 * 16 * sizeof(double);
 }
 
-template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR>
+template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR, int KSREG>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<D, NAX, MIXED, MAXC, MAXRBW, PAIR>;
+    auto kern = admm_kernel<D, NAX, MIXED, MAXC, MAXRBW, PAIR, KSREG>;
     const size_t lds_bytes = admm_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute((const void *)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -597,14 +689,14 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     const int needc = (ncell + 15) / 16, needr = (P.nrb + 3) / 4;
     if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (needc <= 4 && needr <= 1) return launch_admm_t<2, 3, false, 4, 1, true>(P, a, s);
-        if (needc <= 10 && needr <= 3) return launch_admm_t<2, 3, false, 10, 3, true>(P, a, s);
+        if (needc <= 4 && needr <= 1 && P.ks <= 16) return launch_admm_t<2, 3, false, 4, 1, true, 16>(P, a, s);
+        if (needc <= 10 && needr <= 3) return launch_admm_t<2, 3, false, 10, 3, true, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
-        if (needc <= 3 && needr <= 3) return launch_admm_t<3, 2, true, 3, 3, false>(P, a, s);
-        if (needc <= 7 && needr <= 7) return launch_admm_t<3, 2, true, 7, 7, false>(P, a, s);
+        if (needc <= 3 && needr <= 3) return launch_admm_t<3, 2, true, 3, 3, false, 0>(P, a, s);
+        if (needc <= 7 && needr <= 7) return launch_admm_t<3, 2, true, 7, 7, false, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (needc <= 2 && needr <= 2) return launch_admm_t<3, 1, false, 2, 2, false>(P, a, s);
-        if (needc <= 4 && needr <= 4) return launch_admm_t<3, 1, false, 4, 4, false>(P, a, s);
+        if (needc <= 2 && needr <= 2) return launch_admm_t<3, 1, false, 2, 2, false, 0>(P, a, s);
+        if (needc <= 4 && needr <= 4) return launch_admm_t<3, 1, false, 4, 4, false, 0>(P, a, s);
     }
     *why = "horizon too long for the compiled kernel variants";
     return hipErrorInvalidValue;
