@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtg_mpc.so")
+LIB_PATH = os.environ.get("TG_MPC_LIB") or os.path.join(_HERE, "lib", "libtg_mpc.so")
 
 TG_INFTY = 1e30
 TG_OK, TG_E_ARG, TG_E_HIP, TG_E_STATE, TG_E_NUMERIC = 0, -1, -2, -3, -4

@@ -21,6 +21,10 @@
 
 #include "device_types.h"
 
+#ifndef TG_ABLATE
+#define TG_ABLATE 0   // development: 1 = no MFMA, 2 = no rhs phase, 3 = no projection phase
+#endif
+
 namespace tg {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -51,8 +55,11 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
     return d == 0 ? 1.0 : (d == 1 ? dt : c2);
 }
 
-// KSREG > 0: the operator fragments of this wave's row block stay in registers for the whole
-// solve (needs MAXRBW == 1 and ks <= KSREG); KSREG == 0: they are streamed from L2.
+// A workgroup is 8 waves (512 threads): thread (g = tid / 16, t = tid % 16) owns the cells
+// g, g + 32, ... of instance t.  The MFMA work is cut into items (block group, row block)
+// dealt to the waves by the host (StageDev::wi_*), at most MAXIT per wave.
+// KSREG > 0: the operator fragments of the wave's single item stay in registers for the whole
+// solve (needs MAXIT == 1 and ks <= KSREG); KSREG == 0: they are streamed from L2.
 //
 // LDS regions, all [rows][16 instances] of doubles, addressed by absolute double index:
 //   V0  rhs of the linear solve            n_int + S rows (the last S rows take the writes of
@@ -60,15 +67,14 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   WEQ w = rho z - y of the dynamics rows ncell*D + D rows
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
-template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR, int KSREG>
-__global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const BatchArgs a)
+template <int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
+__global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
-    constexpr int MAXGRP = NAX == 3 ? 2 : 1;   // 6-DOF: {x, y} share an operator, z has its own
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int t = tid & 15, g = tid >> 4;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int inst = blockIdx.x * kTileDev + t;
     const bool valid = inst < a.B;
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
     const double dt = P.dt, c2 = P.c2, rho_eq = P.rho_eq;
     constexpr double s3 = 0.86602540378443864676, s2 = 0.70710678118654752440; // sqrt(3)/2, sqrt(2)/2
 
-    for (int j = tid; j < CTAB; j += 256) lds[j] = 0.0;
+    for (int j = tid; j < CTAB; j += kAdmmThreads) lds[j] = 0.0;
     if (tid < NAX * S) {
         const int ax = tid / S, k = tid % S;
         lds[CTAB + tid * 3 + 0] = P.rho_box[ax][k];
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
     double qn = 0.0;
 #pragma unroll
     for (int cc = 0; cc < MAXC; cc++) {
-        const int c = g + 16 * cc;
+        const int c = g + kCellStride * cc;
         const bool act = c < ncell;
         const int ax = act ? c / N1 : 0;
         const int st = act ? c - ax * N1 : 0;
@@ -201,15 +207,15 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
     __syncthreads();
     qn = __longlong_as_double((long long)red[6 * 16 + t]);
 
-    double mreg[KSREG > 0 ? MAXGRP : 1][KSREG > 0 ? KSREG : 1];
+    const int nit = P.wi_cnt[wave];
+    double mreg[KSREG > 0 ? KSREG : 1];
     if constexpr (KSREG > 0) {
+        const int grp = P.wi_grp[wave][0], rb = P.wi_rb[wave][0];
 #pragma unroll
-        for (int grp = 0; grp < MAXGRP; grp++)
-#pragma unroll
-            for (int kk = 0; kk < KSREG; kk++) {
-                const bool in = grp < P.ngrp && kk < ks && wave < nrb;
-                mreg[grp][kk] = in ? P.Mfrag[((size_t)P.grp_op[grp] * nrb * ks + (size_t)wave * ks + kk) * 64 + lane] : 0.0;
-            }
+        for (int kk = 0; kk < KSREG; kk++) {
+            const bool in = nit > 0 && kk < ks;
+            mreg[kk] = in ? P.Mfrag[((size_t)P.grp_op[grp] * nrb * ks + (size_t)rb * ks + kk) * 64 + lane] : 0.0;
+        }
     }
 
     bool done = !valid;
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
     for (int iter = 1; iter <= max_iter; iter++) {
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
 #pragma unroll
-        for (int cc = 0; cc < MAXC; cc++) {
-            const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+        for (int cc = 0; cc < (TG_ABLATE == 2 ? 0 : MAXC); cc++) {
+            const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
             double wn[D], wo[D];
 #pragma unroll
             for (int k = 0; k < D; k++) {
@@ -253,80 +259,70 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
         // D[16 rows x 16 instances] += A[16 x 4] * B[4 x 16]: A = operator fragment (registers
         // when it fits, else streamed from L2 through a prefetch ring), B = rhs rows from LDS
+        {
+            d4 acc0[MAXIT], acc1[PAIR ? MAXIT : 1];
 #pragma unroll
-        for (int grp = 0; grp < MAXGRP; grp++) {
-            if (grp < P.ngrp) {
-                const int b0 = P.grp_first[grp];
-                const bool two = PAIR && P.grp_cnt[grp] == 2;
-                const double *bp0 = v0 + ((size_t)b0 * nb + (lane >> 4)) * 16 + (lane & 15);
-                const double *bp1 = bp0 + (size_t)nb * 16;
-                d4 acc0[MAXRBW], acc1[PAIR ? MAXRBW : 1];
+            for (int it = 0; it < MAXIT; it++) {
+                acc0[it] = (d4){0, 0, 0, 0};
+                if (PAIR) acc1[it] = (d4){0, 0, 0, 0};
+                if (it < nit) {
+                    const int grp = P.wi_grp[wave][it], rb = P.wi_rb[wave][it];
+                    const bool two = PAIR && P.grp_cnt[grp] == 2;
+                    const double *bp0 = v0 + ((size_t)P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15);
+                    const double *bp1 = bp0 + (size_t)nb * 16;
+                    if constexpr (KSREG > 0) {
 #pragma unroll
-                for (int i = 0; i < MAXRBW; i++) acc0[i] = (d4){0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < (PAIR ? MAXRBW : 1); i++) acc1[i] = (d4){0, 0, 0, 0};
-                if constexpr (KSREG > 0) {
-#pragma unroll
-                    for (int kk = 0; kk < KSREG; kk++) {
-                        if (kk < ks) {
-                            const double bf0 = bp0[kk * 64];
-                            acc0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[grp][kk], bf0, acc0[0], 0, 0, 0);
-                            if (PAIR && two) {
-                                const double bf1 = bp1[kk * 64];
-                                acc1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[grp][kk], bf1, acc1[0], 0, 0, 0);
+                        for (int kk = 0; kk < KSREG; kk++) {
+                            if (kk < ks) {
+                                const double bf0 = bp0[kk * 64];
+#if TG_ABLATE != 1
+                                acc0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0, acc0[0], 0, 0, 0);
+                                if (PAIR && two) {
+                                    const double bf1 = bp1[kk * 64];
+                                    acc1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf1, acc1[0], 0, 0, 0);
+                                }
+#else
+                                acc0[0][0] += mreg[kk] * bf0;
+#endif
                             }
                         }
-                    }
-                } else {
-                    constexpr int PD = MAXRBW <= 2 ? 8 : 4;   // k steps in flight
-                    const double *Mop = P.Mfrag + (size_t)P.grp_op[grp] * nrb * ks * 64 + lane;
-                    const double *Mrow[MAXRBW];
-                    double af[PD][MAXRBW];
+                    } else {
+                        constexpr int PD = 8;   // k steps in flight
+                        const double *Mrow = P.Mfrag + ((size_t)P.grp_op[grp] * nrb + rb) * ks * 64 + lane;
+                        double af[PD];
 #pragma unroll
-                    for (int i = 0; i < MAXRBW; i++) {
-                        const int rb = wave + 4 * i;
-                        Mrow[i] = Mop + (size_t)(rb < nrb ? rb : nrb - 1) * ks * 64;
-                    }
+                        for (int p = 0; p < PD; p++) af[p] = Mrow[(size_t)(p < ks ? p : ks - 1) * 64];
+                        for (int kk = 0; kk < ks; kk += PD) {
 #pragma unroll
-                    for (int p = 0; p < PD; p++)
-#pragma unroll
-                        for (int i = 0; i < MAXRBW; i++) af[p][i] = Mrow[i][(size_t)(p < ks ? p : ks - 1) * 64];
-                    for (int kk = 0; kk < ks; kk += PD) {
-#pragma unroll
-                        for (int p = 0; p < PD; p++) {
-                            const int k = kk + p;
-                            if (k < ks) {
-                                const double bf0 = bp0[k * 64];
-                                double bf1 = 0.0;
-                                if (PAIR && two) bf1 = bp1[k * 64];
-                                const int kn = k + PD < ks ? k + PD : k;
-#pragma unroll
-                                for (int i = 0; i < MAXRBW; i++) {
-                                    const double a_ = af[p][i];
-                                    af[p][i] = Mrow[i][(size_t)kn * 64];
-                                    if (wave + 4 * i < nrb) {
-                                        acc0[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf0, acc0[i], 0, 0, 0);
-                                        if (PAIR && two)
-                                            acc1[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf1, acc1[i], 0, 0, 0);
+                            for (int p = 0; p < PD; p++) {
+                                const int k = kk + p;
+                                if (k < ks) {
+                                    const double bf0 = bp0[k * 64];
+                                    const double a_ = af[p];
+                                    af[p] = Mrow[(size_t)(k + PD < ks ? k + PD : k) * 64];
+                                    acc0[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf0, acc0[it], 0, 0, 0);
+                                    if (PAIR && two) {
+                                        const double bf1 = bp1[k * 64];
+                                        acc1[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf1, acc1[it], 0, 0, 0);
                                     }
                                 }
                             }
                         }
                     }
                 }
-                if (!P.separate_xt) __syncthreads();
+            }
+            if (!P.separate_xt) __syncthreads();
 #pragma unroll
-                for (int i = 0; i < MAXRBW; i++) {
-                    const int rb = wave + 4 * i;
-                    if (rb < nrb) {
-                        double *o0 = vx + ((size_t)b0 * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
+            for (int it = 0; it < MAXIT; it++) {
+                if (it < nit) {
+                    const int grp = P.wi_grp[wave][it], rb = P.wi_rb[wave][it];
+                    double *o0 = vx + ((size_t)P.grp_first[grp] * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
 #pragma unroll
-                        for (int r = 0; r < 4; r++) o0[r * 64] = acc0[i][r];
-                        if (PAIR && two) {
-                            double *o1 = o0 + (size_t)nb * 16;
+                    for (int r = 0; r < 4; r++) o0[r * 64] = acc0[it][r];
+                    if (PAIR && P.grp_cnt[grp] == 2) {
+                        double *o1 = o0 + (size_t)nb * 16;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) o1[r * 64] = acc1[i][r];
-                        }
+                        for (int r = 0; r < 4; r++) o1[r * 64] = acc1[it][r];
                     }
                 }
             }
@@ -334,8 +330,8 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
         __syncthreads();
         // -------------------------------------------------------- relaxation, projection, dual
 #pragma unroll
-        for (int cc = 0; cc < MAXC; cc++) {
-            const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+        for (int cc = 0; cc < (TG_ABLATE == 3 ? 0 : MAXC); cc++) {
+            const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
             const double *xin = vx + i_var[cc];
             const double *xpr = lds + i_prev[cc];
             const double *ct = lds + i_ct[cc];
@@ -397,7 +393,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
             // x -> VX, y of the dynamics / mixed rows -> WEQ / WMX (restored below)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+                const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
                 double *xo = vx + i_var[cc];
 #pragma unroll
                 for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
@@ -414,7 +410,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
             double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int c = g + 16 * cc;
+                const int c = g + kCellStride * cc;
                 if (c < ncell) {
                     const int ax = c / N1, st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
@@ -516,7 +512,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                 done = true;
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551)
                 for (int cc = 0; cc < MAXC; cc++) {
-                    const int c = g + 16 * cc;
+                    const int c = g + kCellStride * cc;
                     if (c < ncell) {
                         const int ax = c / N1, st = c - ax * N1;
                         const double *xs = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
@@ -533,7 +529,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
                 if (a.warm_out) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
-                        const int c = g + 16 * cc;
+                        const int c = g + kCellStride * cc;
                         if (c < ncell) {
                             const int ax = c / N1, st = c - ax * N1;
                             int abase = 0;
@@ -568,7 +564,7 @@ __global__ __launch_bounds__(256) void admm_kernel(const StageDev P, const Batch
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = (g + 16 * cc) < ncell ? g + 16 * cc : ncell;
+                const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
 #pragma unroll
                 for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
                 if (MIXED) {
@@ -670,33 +666,35 @@ size_t admm_lds_bytes(const StageDev &P)
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + 7 * 16 * sizeof(double);
 }
 
-template <int D, int NAX, bool MIXED, int MAXC, int MAXRBW, bool PAIR, int KSREG>
+template <int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<D, NAX, MIXED, MAXC, MAXRBW, PAIR, KSREG>;
+    auto kern = admm_kernel<D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG>;
     const size_t lds_bytes = admm_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute((const void *)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     const int grid = (a.B + kTileDev - 1) / kTileDev;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, s, P, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kAdmmThreads), lds_bytes, s, P, a);
     return hipGetLastError();
 }
 
 hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why)
 {
     const int ncell = P.nax * (P.N + 1);
-    const int needc = (ncell + 15) / 16, needr = (P.nrb + 3) / 4;
+    const int needc = (ncell + kCellStride - 1) / kCellStride;
+    int needi = 0;
+    for (int w = 0; w < kAdmmWaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
     if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (needc <= 4 && needr <= 1 && P.ks <= 16) return launch_admm_t<2, 3, false, 4, 1, true, 16>(P, a, s);
-        if (needc <= 10 && needr <= 3) return launch_admm_t<2, 3, false, 10, 3, true, 0>(P, a, s);
+        if (needc <= 2 && needi <= 1 && P.ks <= 16) return launch_admm_t<2, 3, false, 2, 1, true, 16>(P, a, s);
+        if (needc <= 5 && needi <= 3) return launch_admm_t<2, 3, false, 5, 3, true, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
-        if (needc <= 3 && needr <= 3) return launch_admm_t<3, 2, true, 3, 3, false, 0>(P, a, s);
-        if (needc <= 7 && needr <= 7) return launch_admm_t<3, 2, true, 7, 7, false, 0>(P, a, s);
+        if (needc <= 2 && needi <= 2) return launch_admm_t<3, 2, true, 2, 2, false, 0>(P, a, s);
+        if (needc <= 4 && needi <= 4) return launch_admm_t<3, 2, true, 4, 4, false, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (needc <= 2 && needr <= 2) return launch_admm_t<3, 1, false, 2, 2, false, 0>(P, a, s);
-        if (needc <= 4 && needr <= 4) return launch_admm_t<3, 1, false, 4, 4, false, 0>(P, a, s);
+        if (needc <= 1 && needi <= 1 && P.ks <= 24) return launch_admm_t<3, 1, false, 1, 1, false, 24>(P, a, s);
+        if (needc <= 2 && needi <= 2) return launch_admm_t<3, 1, false, 2, 2, false, 0>(P, a, s);
     }
     *why = "horizon too long for the compiled kernel variants";
     return hipErrorInvalidValue;

@@ -8,6 +8,9 @@ constexpr int kTileDev = 16;            // instances per workgroup = MFMA f64 16
 constexpr double TG_DEV_INFTY = 1e30;   // OsqpEigen::INFTY
 constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2;
 constexpr int kMaxAxes = 3, kMaxSlots = 4;
+constexpr int kAdmmThreads = 512, kAdmmWaves = kAdmmThreads / 64;   // ADMM workgroup
+constexpr int kCellStride = kAdmmThreads / kTileDev;                // cells g, g + 32, ... per thread
+constexpr int kMaxItems = 8;                                        // MFMA work items per wave
 
 // One QP stage as the ADMM kernel sees it.  Every axis of the model is a chain of
 // integrators of order D (6-DOF: D = 2, states p,v, input a; 12-state stages: D = 3,
@@ -20,6 +23,9 @@ struct StageDev {
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];
     int separate_xt;
+    // MFMA work items (block group, row block) of every wave
+    int wi_cnt[kAdmmWaves];
+    unsigned char wi_grp[kAdmmWaves][kMaxItems], wi_rb[kAdmmWaves][kMaxItems];
     const double *Mfrag;         // [nops][nrb][ks][64] operator fragments, MFMA A-operand order
     double dt, c2;               // c2 = dt^2/2 (position <- acceleration coupling, D = 3)
     double qw[kMaxAxes];         // q(position slot) = qw * ref            (qw = -state weight)

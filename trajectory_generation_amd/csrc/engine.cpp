@@ -95,6 +95,27 @@ struct DevStage {
             dev.grp_first[dev.ngrp] = b; dev.grp_cnt[dev.ngrp] = cnt; dev.grp_op[dev.ngrp] = sp.op_of_block[b];
             dev.ngrp++; b += cnt;
         }
+        // deal the (group, row block) MFMA items: longest first onto the least loaded SIMD
+        // (waves w and w + 4 of a workgroup share a SIMD), then onto its less loaded wave
+        {
+            struct Item { int grp, rb, cost; };
+            std::vector<Item> items;
+            for (int gi = 0; gi < dev.ngrp; gi++)
+                for (int rb = 0; rb < dev.nrb; rb++) items.push_back({gi, rb, dev.grp_cnt[gi]});
+            std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+            int simd_load[4] = {0, 0, 0, 0}, wave_load[kAdmmWaves] = {0};
+            for (int w = 0; w < kAdmmWaves; w++) dev.wi_cnt[w] = 0;
+            for (const Item &it : items) {
+                int sd = 0;
+                for (int k = 1; k < 4; k++) if (simd_load[k] < simd_load[sd]) sd = k;
+                int w = wave_load[sd] <= wave_load[sd + 4] ? sd : sd + 4;
+                if (dev.wi_cnt[w] >= kMaxItems) return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
+                dev.wi_grp[w][dev.wi_cnt[w]] = (unsigned char)it.grp;
+                dev.wi_rb[w][dev.wi_cnt[w]] = (unsigned char)it.rb;
+                dev.wi_cnt[w]++;
+                simd_load[sd] += it.cost; wave_load[w] += it.cost;
+            }
+        }
         dev.Mfrag = d_Mfrag;
         dev.dt = mdl.Ad[1] != 0.0 ? mdl.Ad[1] : mdl.Ad[3];   // Ad(0,1) (triple integrator) or Ad(0,3) (6-DOF)
         dev.c2 = six ? 0.0 : mdl.Ad[2];
