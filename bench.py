@@ -39,7 +39,7 @@ def flops_per_iteration(model, N):
     return 2 * ((8 * N + 6) ** 2 + 2 * (4 * N + 3) ** 2)
 
 
-def cpu_baseline(model, N, seed_off):
+def cpu_baseline(model, N, seed_off, eps, rho, rho_rows):
     """Reference CPU path restated (OSQP algorithm with its default settings, one instance at a
     time on one core, as the reference runs it) on a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -48,25 +48,28 @@ def cpu_baseline(model, N, seed_off):
     if N >= 50:
         sample //= 8
     out = {}
-    for kind, mk in (("osqp_defaults", lambda: O.default_settings(warm_start=0)),
+    fixed = lambda r: O.fixed_rho_settings(r, warm_start=0, eps_abs=eps, eps_rel=eps)
+    for kind, mk in (("osqp_defaults", lambda: O.default_settings(warm_start=0, eps_abs=eps, eps_rel=eps)),
                      ("engine_algorithm", None)):
+        if mk:
+            O.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)    # OSQP: one rho for all inequality rows
+        else:
+            O.match_rho_classes(rho_rows)                # the engine's fixed per-class step sizes
         if model == "6dof":
             p = O.mpc6_params(N=N)
             x0, ref = O.synth_mpc6(SEED + seed_off, N, 0.1, sample)
-            s = mk() if mk else O.fixed_rho_settings(1000.0, warm_start=0)
+            s = mk() if mk else fixed(rho)
             t = time.perf_counter(); r = O.mpc6_batch(p, s, x0, ref); dt = time.perf_counter() - t
         else:
             p = O.mpc12_params(N=N)
             x0, ref = O.synth_mpc12(SEED + seed_off, N, 0.1, sample)
-            s = mk() if mk else {"xy": O.fixed_rho_settings(1000.0, warm_start=0),
-                                 "z": O.fixed_rho_settings(1000.0, warm_start=0),
-                                 "yaw": O.fixed_rho_settings(200.0, warm_start=0)}
+            s = mk() if mk else {k: fixed(rho[i]) for i, k in enumerate(("xy", "z", "yaw"))}
             t = time.perf_counter(); r = O.mpc12_batch(p, s, x0, ref); dt = time.perf_counter() - t
         out[kind] = dict(value=sample / dt, iters_mean=float(np.mean(r["iters"])), solved=float(r["n_ok"]) / sample)
     return {"value": out["osqp_defaults"]["value"], "unit": "solves/s", "cores": 1, "kind": "port",
             "sample": "%d instances of the same seeded workload, one at a time on one core; OSQP algorithm "
                       "restated with its default settings (Ruiz scaling 10, adaptive rho every 50 iterations, "
-                      "eps 1e-3), dense Cholesky of the reduced KKT matrix; upstream OSQP 25b6b39 is not "
+                      "eps as the GPU run), dense Cholesky of the reduced KKT matrix; upstream OSQP 25b6b39 is not "
                       "available offline" % sample,
             "iters_mean": out["osqp_defaults"]["iters_mean"], "solved_frac": out["osqp_defaults"]["solved"],
             "same_algorithm_as_gpu": out["engine_algorithm"]}
@@ -184,7 +187,7 @@ def main():
     }
     del out["config"]["model"]
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(model, N, seed_off)
+        out["cpu_baseline"] = cpu_baseline(model, N, seed_off, args.eps, out["config"]["rho"], eng.rho_rows())
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

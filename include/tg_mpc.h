@@ -72,6 +72,11 @@ typedef struct {
     double eps_abs, eps_rel;  /* 1e-3 */
     int    max_iter;          /* 4000 */
     int    check_termination; /* 25   */
+    /* multipliers of rho on the box rows of positions, velocities, accelerations (12-state)
+     * and inputs; the XY mixed rows use the velocity / acceleration entries.  OSQP has one rho
+     * for all inequality rows and adapts it at run time; a fixed rho per class of row takes
+     * the place of that adaptation.  0 = the built-in choice, 1 = OSQP's uniform rho. */
+    double rho_scale[4];
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

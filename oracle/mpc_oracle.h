@@ -70,6 +70,9 @@ osqp_work *osqp_setup(int n, int m, const double *P, const double *A, const doub
 void osqp_cleanup(osqp_work *w);
 int  osqp_update_bounds(osqp_work *w, const double *l, const double *u); /* 0 ok */
 int  osqp_update_lin_cost(osqp_work *w, const double *q);
+/* Extension used by the engine's fixed-rho mode: rho of inequality row i becomes
+ * scale[i] * rho (OSQP itself only distinguishes equality / inequality / unbounded rows). */
+int  osqp_set_rho_scale(osqp_work *w, const double *scale);
 void osqp_warm_start(osqp_work *w, const double *x, const double *y);
 int  osqp_solve(osqp_work *w); /* returns status */
 void osqp_get_solution(const osqp_work *w, double *x, double *y);
@@ -134,6 +137,11 @@ void qp12_update_yaw(const mpc12_params *p, const double *yaw0, const double *ya
                      double *q, double *l, double *u);
 void qp12_merge(int N, const double *xy_sol, const double *z_sol, const double *yaw_sol,
                 double *x_opt /*12(N+1)*/, double *u_opt /*4N*/);
+
+/* Per-class rho multipliers applied by mpc6_create / mpc12_create to the box rows of
+ * positions, velocities, accelerations (12-state) and inputs, and to the XY mixed rows
+ * (velocity class for rows 0-3, acceleration class for rows 4-5).  Default {1,1,1,1}. */
+void mpc_set_rho_class_scale(double pos, double vel, double acc, double input);
 
 /* ------------------------------------------------------------------ whole mpcLoop   */
 

@@ -327,6 +327,32 @@ void qp12_build(const mpc12_params *p, int family, double *P, double *A, double 
     }
 }
 
+/* ---------------------------------------------------------------- per-class rho scale */
+static double g_cls[4] = {1.0, 1.0, 1.0, 1.0};
+void mpc_set_rho_class_scale(double pos, double vel, double acc, double input)
+{
+    g_cls[0] = pos; g_cls[1] = vel; g_cls[2] = acc; g_cls[3] = input;
+}
+
+static void apply_class_scale(osqp_work *w, int family, int N)
+{
+    if (g_cls[0] == 1.0 && g_cls[1] == 1.0 && g_cls[2] == 1.0 && g_cls[3] == 1.0) return;
+    int n, m, nx, nu;
+    qp_dims(family, N, &n, &m, &nx, &nu);
+    int Nx = nx * (N + 1), Nu = nu * N;
+    double *sc = (double *)calloc(m, sizeof(double));
+    for (int r = 0; r < m; r++) sc[r] = 1.0;
+    for (int i = 0; i <= N; i++)
+        for (int a = 0; a < nx; a++) {
+            int cls = family == FAM_6DOF ? (a < 3 ? 0 : 1) : a % 3;
+            sc[Nx + nx * i + a] = g_cls[cls];
+        }
+    for (int r = 0; r < Nu; r++) sc[2 * Nx + r] = g_cls[3];
+    for (int r = 2 * Nx + Nu; r < m; r++) sc[r] = g_cls[(r - 2 * Nx - Nu) % 6 < 4 ? 1 : 2];
+    osqp_set_rho_scale(w, sc);
+    free(sc);
+}
+
 /* ---------------------------------------------------------------- mpcLoop, 6-DOF */
 struct mpc6_oracle {
     mpc6_params p;
@@ -350,6 +376,7 @@ mpc6_oracle *mpc6_create(const mpc6_params *p, const osqp_settings *s)
     o->w = osqp_setup(o->n, o->m, P, A, o->q, o->l, o->u, s);
     free(P); free(A);
     if (!o->w) { mpc6_destroy(o); return NULL; }
+    apply_class_scale(o->w, FAM_6DOF, p->N);
     return o;
 }
 
@@ -436,6 +463,7 @@ mpc12_oracle *mpc12_create3(const mpc12_params *p, const osqp_settings *s_xy,
         o->w[f] = osqp_setup(o->n[f], o->m[f], P, A, o->q[f], o->l[f], o->u[f], ss[f]);
         free(P); free(A);
         if (!o->w[f]) { mpc12_destroy(o); return NULL; }
+        apply_class_scale(o->w[f], f, N);
     }
     o->xyref = (double *)calloc((size_t)6 * (N + 1), sizeof(double));
     o->zref = (double *)calloc((size_t)3 * (N + 1), sizeof(double));

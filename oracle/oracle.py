@@ -122,6 +122,8 @@ def lib():
         L.mpc12_create3.restype = C.c_void_p
         L.mpc12_create3.argtypes = [C.POINTER(Mpc12Params)] + [C.POINTER(Settings)] * 3
         L.mpc12_batch3.argtypes = [C.POINTER(Mpc12Params)] + [C.POINTER(Settings)] * 3 + [C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]
+        L.osqp_set_rho_scale.argtypes = [C.c_void_p, _dp]
+        L.mpc_set_rho_class_scale.argtypes = [C.c_double] * 4
         L.synth_uniform.restype = C.c_double
         L.synth_uniform.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]
         L.synth_mpc6.argtypes = [C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp]
@@ -174,6 +176,32 @@ def mpc12_params(N=20, dt=0.1, enable_control_smoothing=False,
     p.xy_max_accel, p.z_max_accel, p.yaw_max_accel = max_accel
     p.xy_max_jerk, p.z_max_jerk, p.yaw_max_jerk = max_jerk
     return p
+
+
+def set_rho_class_scale(pos=1.0, vel=1.0, acc=1.0, inp=1.0):
+    """Per-class multipliers of rho used by Mpc6 / Mpc12 / mpc*_batch objects created afterwards."""
+    lib().mpc_set_rho_class_scale(pos, vel, acc, inp)
+
+
+def match_rho_classes(stages):
+    """Read the per-class multipliers back from per-row rho vectors and make them the ones the
+    oracle uses.  stages: iterable of (rho_vec, rho, nx, N) in the reference's row ordering
+    (dynamics | state box | input box | mixed).  Rows with infinite bounds carry rho_min and say
+    nothing about their class; such a class keeps multiplier 1."""
+    cls = [1.0, 1.0, 1.0, 1.0]
+    for rho_vec, rho, nx, N in stages:
+        Nx = nx * (N + 1)
+        rows = {0: Nx + 0, 3: 2 * Nx}
+        if nx == 6 and len(rho_vec) == 2 * Nx + 3 * N:      # 6-DOF: p(3), v(3); only p_z is bounded
+            rows[0], rows[1] = Nx + 2, Nx + 3
+        else:                                                 # chains p, v, a
+            rows[1], rows[2] = Nx + 1, Nx + 2
+        for k, r in rows.items():
+            f = rho_vec[r] / rho
+            if f > 1e-3:
+                cls[k] = float(f)
+    set_rho_class_scale(*cls)
+    return tuple(cls)
 
 
 def dims(family, N):
@@ -273,6 +301,11 @@ class Osqp:
                 raise ValueError("update_bounds rc=%d" % rc)
         if q is not None:
             lib().osqp_update_lin_cost(self._h, _p(np.ascontiguousarray(q)))
+
+    def set_rho_scale(self, scale):
+        rc = lib().osqp_set_rho_scale(self._h, _p(np.ascontiguousarray(scale, dtype=np.float64)))
+        if rc:
+            raise RuntimeError("refactorisation failed")
 
     def warm_start(self, x, y):
         lib().osqp_warm_start(self._h, _p(np.ascontiguousarray(x)), _p(np.ascontiguousarray(y)))

@@ -40,6 +40,7 @@ struct osqp_work {
     double *q, *l, *u;     /* scaled */
     double *D, *E, *Dinv, *Einv, c, cinv;
     double *rho_vec, *rho_inv_vec;
+    double *rho_scale;     /* optional per-row multiplier of rho on inequality rows (NULL: 1) */
     int *constr_type;
     double *L;             /* dense Cholesky factor of the reduced matrix, n x n lower */
     double *x, *z, *y, *x_prev, *z_prev, *xt, *zt, *delta_x, *delta_y;
@@ -204,7 +205,8 @@ static void apply_rho(osqp_work *w)
 {
     for (int i = 0; i < w->m; i++) {
         double r = w->constr_type[i] == -1 ? RHO_MIN
-                 : w->constr_type[i] == 1 ? RHO_EQ_OVER_RHO_INEQ * w->s.rho : w->s.rho;
+                 : w->constr_type[i] == 1 ? RHO_EQ_OVER_RHO_INEQ * w->s.rho
+                 : (w->rho_scale ? w->rho_scale[i] * w->s.rho : w->s.rho);
         w->rho_vec[i] = r; w->rho_inv_vec[i] = 1.0 / r;
     }
 }
@@ -307,7 +309,7 @@ void osqp_cleanup(osqp_work *w)
     if (!w) return;
     csr_free(&w->P); csr_free(&w->A); csr_free(&w->At);
     free(w->q); free(w->l); free(w->u); free(w->D); free(w->E); free(w->Dinv); free(w->Einv);
-    free(w->rho_vec); free(w->rho_inv_vec); free(w->constr_type); free(w->L);
+    free(w->rho_vec); free(w->rho_inv_vec); free(w->rho_scale); free(w->constr_type); free(w->L);
     free(w->x); free(w->z); free(w->y); free(w->x_prev); free(w->z_prev); free(w->xt); free(w->zt);
     free(w->delta_x); free(w->delta_y); free(w->Ax); free(w->Px); free(w->Aty); free(w->wn);
     free(w->wm); free(w->sol_x); free(w->sol_y);
@@ -334,6 +336,14 @@ int osqp_update_lin_cost(osqp_work *w, const double *q)
     for (int j = 0; j < w->n; j++) w->q[j] = w->c * w->D[j] * q[j];
     w->status = ORACLE_UNSOLVED;
     return 0;
+}
+
+int osqp_set_rho_scale(osqp_work *w, const double *scale)
+{
+    if (!w->rho_scale) w->rho_scale = dalloc(w->m);
+    memcpy(w->rho_scale, scale, sizeof(double) * w->m);
+    apply_rho(w);
+    return factor(w);
 }
 
 void osqp_warm_start(osqp_work *w, const double *x, const double *y)

@@ -14,10 +14,19 @@ def pytest_configure(config):
 
 
 @pytest.fixture(scope="session")
-def oracle():
+def _oracle_module():
     from oracle import oracle as O
     O.build()
     return O
+
+
+@pytest.fixture
+def oracle(_oracle_module):
+    # the per-class rho multipliers are process-global in the oracle: every test starts from
+    # OSQP's uniform rho and opts in to an engine's multipliers with match_rho_classes()
+    _oracle_module.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    yield _oracle_module
+    _oracle_module.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
 
 
 @pytest.fixture(scope="session")

@@ -62,8 +62,15 @@ def test_matrices_bit_exact_6dof(tg, oracle, N, smooth):
     K = qp["P"] + 1e-6 * np.eye(qp["n"]) + qp["A"].T @ (rho[:, None] * qp["A"])
     assert np.abs(K @ eng.get(capi.TG_MAT_KINV) - np.eye(qp["n"])).max() < 1e-10
     # rho classes as OSQP assigns them: equality 1e3 rho, unbounded 1e-6, else rho
-    w = oracle.Osqp(qp["P"], qp["A"], qp["q"], qp["l"], qp["u"], oracle.fixed_rho_settings(eng.rho))
-    np.testing.assert_array_equal(rho, w.rho_vec())
+    # (uniform rho requested here; the built-in per-class multipliers are covered by the solve tests)
+    eng1 = tg.BatchedMPC6(p, tg.make_opts(rho_scale=(1, 1, 1, 1)))
+    w = oracle.Osqp(qp["P"], qp["A"], qp["q"], qp["l"], qp["u"], oracle.fixed_rho_settings(eng1.rho))
+    np.testing.assert_array_equal(eng1.get(capi.TG_VEC_RHO), w.rho_vec())
+    # built-in multipliers only touch inequality rows and are read back exactly
+    cls = oracle.match_rho_classes(eng.rho_rows())
+    same = rho == eng1.get(capi.TG_VEC_RHO)
+    Nx = 6 * (N + 1)
+    assert same[:Nx].all() and cls == (20.0, 3.0, 1.0, 5.0)
 
 
 @pytest.mark.parametrize("N,B", [(5, 1), (20, 37), (50, 16)])
@@ -128,14 +135,17 @@ def test_assembly_and_matrices_bit_exact_12state(tg, oracle):
 
 
 # ---------------------------------------------------------------- solve vs the oracle (same algorithm)
-@pytest.mark.parametrize("N,B,eps,smooth", [(5, 1, 1e-3, False), (10, 16, 1e-3, True), (20, 64, 1e-3, False),
-                                            (20, 37, 1e-5, False), (20, 48, 1e-3, True), (50, 32, 1e-3, False)])
-def test_solve_matches_oracle_6dof(tg, oracle, N, B, eps, smooth):
+@pytest.mark.parametrize("N,B,eps,smooth,scale", [
+    (5, 1, 1e-3, False, None), (10, 16, 1e-3, True, None), (20, 64, 1e-3, False, None),
+    (20, 37, 1e-5, False, None), (20, 48, 1e-3, True, None), (50, 32, 1e-3, False, None),
+    (20, 64, 1e-3, False, (1, 1, 1, 1)), (50, 16, 1e-3, False, (1, 1, 1, 1)), (20, 33, 1e-4, True, (7, 2, 1, 0.5))])
+def test_solve_matches_oracle_6dof(tg, oracle, N, B, eps, smooth, scale):
     kw = dict(N=N, enable_control_smoothing=smooth)
     p, op = _p6_pair(tg, oracle, **kw)
-    eng = tg.BatchedMPC6(p, tg.make_opts(eps_abs=eps, eps_rel=eps))
+    eng = tg.BatchedMPC6(p, tg.make_opts(eps_abs=eps, eps_rel=eps, rho_scale=scale or (0, 0, 0, 0)))
     x0, ref = oracle.synth_mpc6(SEED + 2, N, 0.1, B)
     r = eng.solve_host(x0, ref)
+    oracle.match_rho_classes(eng.rho_rows())
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, eps_abs=eps, eps_rel=eps, warm_start=0), x0, ref)
     assert (r["status"] == 1).all() and (ro["status"] == 1).all()
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -149,6 +159,7 @@ def test_solve_matches_oracle_12state(tg, oracle):
     x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B)
     r = eng.solve_host(x12, ref12)
     s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
+    oracle.match_rho_classes(eng.rho_rows())
     ro = oracle.mpc12_batch(op, s, x12, ref12)
     assert (r["status"] == 1).all() and (ro["status"] == 1).all()
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -162,7 +173,7 @@ def test_12state_stage_by_stage_with_injected_upstream(tg, oracle, golden_dir):
     import torch
     g = np.load(os.path.join(golden_dir, "rand_12state_N20.npz"))
     N, B = int(g["N"]), g["x0"].shape[0]
-    eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(eps_abs=1e-7, eps_rel=1e-7, max_iter=20000))
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(eps_abs=1e-8, eps_rel=1e-8, max_iter=40000))
     buf = eng.alloc(B)
     _to_dev(buf, g["x0"], g["ref"])
     buf["X"][:, :B] = torch.from_numpy(np.ascontiguousarray(g["X"].T)).cuda()
@@ -294,6 +305,7 @@ def test_warm_start_matches_oracle(tg, oracle):
     a = eng.solve_host(x0, ref, warm=True)
     b = eng.solve_host(x1, ref1, warm=True)
     cold = eng.solve_host(x1, ref1, warm=False)
+    oracle.match_rho_classes(eng.rho_rows())
     for i in range(B):
         m = oracle.Mpc6(op, oracle.fixed_rho_settings(eng.rho))
         ra = m.loop(x0[i], ref[i]); rb = m.loop(x1[i], ref1[i])
@@ -318,6 +330,7 @@ def test_ragged_empty_and_padding(tg, oracle):
     buf["X"].fill_(-7.0); buf["U"].fill_(-7.0); buf["status"].fill_(99)
     eng.solve(buf)
     torch.cuda.synchronize()
+    oracle.match_rho_classes(eng.rho_rows())
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
     assert np.abs(buf["X"][:, :B].cpu().numpy().T - ro["X"]).max() < 1e-9
     assert (buf["X"][:, B:] == -7.0).all() and (buf["U"][:, B:] == -7.0).all()   # padding untouched

@@ -75,7 +75,7 @@ struct DevStage {
     int init(const StageModel &mdl, const tg_solver_opts &o, double rho)
     {
         std::string err;
-        if (!build_stage(mdl, rho, o.sigma, sp, err)) return fail(TG_E_NUMERIC, err);
+        if (!build_stage(mdl, rho, o.sigma, o.rho_scale, sp, err)) return fail(TG_E_NUMERIC, err);
         int rc;
         if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
         if ((rc = upload(sp.q_w, &d_qw))) return rc;
@@ -250,6 +250,8 @@ static int check_opts(const tg_solver_opts &o)
     if (!(o.sigma > 0) || !(o.alpha > 0 && o.alpha < 2) || !(o.eps_abs >= 0) || !(o.eps_rel >= 0) ||
         o.max_iter < 1 || o.check_termination < 1)
         return fail(TG_E_ARG, "invalid solver options");
+    for (int k = 0; k < 4; k++)
+        if (!(o.rho_scale[k] >= 0)) return fail(TG_E_ARG, "rho_scale entries must be >= 0");
     return TG_OK;
 }
 
@@ -259,6 +261,7 @@ void tg_default_opts(tg_solver_opts *o)
 {
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
     o->max_iter = 4000; o->check_termination = 25;
+    for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }
 int tg_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }

@@ -16,9 +16,12 @@ def _torch():
 
 
 def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000,
-              check_termination=25):
+              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0)):
+    """rho <= 0 and rho_scale entries of 0 select the engine's built-in choices; rho_scale is
+    (position, velocity, acceleration, input) multipliers of rho on the box rows."""
     o = capi.SolverOpts()
     capi.load().tg_default_opts(C.byref(o))
+    o.rho_scale[:] = [float(v) for v in rho_scale]
     o.rho, o.sigma, o.alpha = rho, sigma, alpha
     o.eps_abs, o.eps_rel, o.max_iter, o.check_termination = eps_abs, eps_rel, max_iter, check_termination
     return o
@@ -99,6 +102,10 @@ class BatchedMPC6:
     @property
     def rho(self):
         return self.lib.tg_mpc6_rho(self._h)
+
+    def rho_rows(self):
+        """[(per-row rho vector, rho, nx, N)]: the step sizes the solver was built with."""
+        return [(self.get(capi.TG_VEC_RHO), self.rho, 6, self.N)]
 
     def get(self, which):
         N = self.N
@@ -195,6 +202,10 @@ class BatchedMPC12:
 
     def rho(self, stage):
         return self.lib.tg_mpc12_rho(self._h, self.STAGES[stage])
+
+    def rho_rows(self):
+        N = self.params.N
+        return [(self.get(s, capi.TG_VEC_RHO), self.rho(s), 6 if s == "xy" else 3, N) for s in ("xy", "z", "yaw")]
 
     def get(self, stage, which):
         n, m = self.dims(stage)
