@@ -77,6 +77,10 @@ typedef struct {
      * for all inequality rows and adapts it at run time; a fixed rho per class of row takes
      * the place of that adaptation.  0 = the built-in choice, 1 = OSQP's uniform rho. */
     double rho_scale[4];
+    /* OSQP's eps_prim_inf (1e-4): tolerance of the primal infeasibility certificate tested at
+     * every termination check; 0 switches the test off.  Dual infeasibility cannot occur: the
+     * inputs are boxed and the dynamics rows tie every state to them. */
+    double eps_prim_inf;
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

@@ -341,14 +341,44 @@ def test_ragged_empty_and_padding(tg, oracle):
 
 
 def test_infeasible_instance_reports_failure(tg, oracle):
+    """OSQP's primal infeasibility certificate, tested at every termination check: same status
+    and detection iteration as the oracle; without the test the instance runs to max_iter."""
     N = 10
-    p, _ = _p6_pair(tg, oracle, N=N)
-    eng = tg.BatchedMPC6(p, tg.make_opts(max_iter=500))
+    p, op = _p6_pair(tg, oracle, N=N)
     x0, ref = oracle.synth_mpc6(3, N, 0.1, 4)
     x0[2, 3] = 50.0                                 # |v_x(0)| > v_max: step-0 box contradicts x(0) = x0
+    eng = tg.BatchedMPC6(p)
+    sentinel = np.full((4, 6 * (N + 1)), -7.0)
     r = eng.solve_host(x0, ref)
-    assert r["status"][2] != 1 and r["iters"][2] == 500
+    oracle.match_rho_classes(eng.rho_rows())
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
+    assert r["status"][2] == -3 and ro["status"][2] == oracle.PRIMAL_INFEASIBLE
+    np.testing.assert_array_equal(r["iters"], ro["iters"])
     assert (np.delete(r["status"], 2) == 1).all()   # the neighbours in the same tile are unaffected
+    keep = [0, 1, 3]
+    assert np.abs(r["X"][keep] - ro["X"][keep]).max() < 1e-9
+    off = tg.BatchedMPC6(p, tg.make_opts(max_iter=500, eps_prim_inf=0.0))
+    r = off.solve_host(x0, ref)
+    assert r["status"][2] == -2 and r["iters"][2] == 500
+
+
+def test_12state_failed_stage_gates_the_later_ones(tg, oracle):
+    """An instance whose XY problem is infeasible (bounds derived from its Z solution): XY reports
+    primal infeasible, the yaw stage is not attempted (MPC12STATE::mpcLoop returns at the first
+    failing stage, mpc_12state.cpp:1374-1453); statuses and iteration counts match the oracle."""
+    N, B, first = 20, 16, 1088                       # instance 1092 of the benchmark batch
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N))
+    op = oracle.mpc12_params(N=N)
+    x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B, first)
+    r = eng.solve_host(x12, ref12)
+    s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
+    oracle.match_rho_classes(eng.rho_rows())
+    ro = oracle.mpc12_batch(op, s, x12, ref12)
+    np.testing.assert_array_equal(r["status"], ro["status"])
+    np.testing.assert_array_equal(r["iters"], ro["iters"])
+    assert tuple(r["status"][4]) == (1, -3, -10) and r["iters"][4][2] == 0
+    ok = (r["status"] == 1).all(1)
+    assert ok.sum() == B - 1 and np.abs(r["X"][ok] - ro["X"][ok]).max() < 1e-8
 
 
 # ---------------------------------------------------------------- full benchmark sizes: properties

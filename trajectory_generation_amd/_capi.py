@@ -40,7 +40,8 @@ class Mpc12Params(C.Structure):
 class SolverOpts(C.Structure):
     _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
                 ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int),
-                ("check_termination", C.c_int), ("rho_scale", C.c_double * 4)]
+                ("check_termination", C.c_int), ("rho_scale", C.c_double * 4),
+                ("eps_prim_inf", C.c_double)]
 
 
 # every symbol include/tg_mpc.h declares: name -> (restype, argtypes)

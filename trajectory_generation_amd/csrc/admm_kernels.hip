@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "device_types.h"
 
 #ifndef TG_ABLATE
@@ -76,7 +78,10 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     const int t = tid & 15, g = tid >> 4;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int inst = blockIdx.x * kTileDev + t;
-    const bool valid = inst < a.B;
+    // an instance whose upstream stage did not reach "solved" is not attempted
+    // (MPC12STATE::mpcLoop returns at the first failing stage, mpc_12state.cpp:1374-1453)
+    const bool gated = inst < a.B && a.gate && a.gate[inst] != TG_DEV_SOLVED;
+    const bool valid = inst < a.B && !gated;
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
 
@@ -86,7 +91,8 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     const int WMX = WEQ + (ncell * D + D) * 16;
     const int ZERO = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);
     const int CTAB = ZERO + 8 * 16;                                          // [NAX][S][3] rho, lb, ub
-    unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [7][16]
+    unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
+    double *rsum = (double *)(red + 9 * 16);                                        // [8 waves][16] partial sums
     double *v0 = lds + V0, *vx = lds + VX;
 
     const double sigma = P.sigma, alpha = P.alpha, oma = 1.0 - P.alpha;
@@ -219,9 +225,22 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     }
 
     bool done = !valid;
+    if (gated && g == 0) {
+        if (a.status) a.status[inst] = TG_DEV_UNSOLVED;
+        if (a.iters) a.iters[inst] = 0;
+    }
     const int max_iter = P.max_iter, check = P.check;
+    const double eps_pinf = P.eps_prim_inf;
 
-    for (int iter = 1; iter <= max_iter; iter++) {
+    // One ADMM iteration.  CHK marks an iteration that is followed by a termination check: it
+    // also needs the step delta_y = y+ - y of every row for OSQP's primal infeasibility test.
+    // The dynamics / mixed rows' part goes to WEQ / WMX in place of w (restored after the check),
+    // the thread's own part of A' delta_y stays in registers (part), ||delta_y||_inf and
+    // u'(dy)+ + l'(dy)- are accumulated (pin_n, pin_l).
+    double part[MAXC][S];
+    double pin_n = 0.0, pin_l = 0.0;
+    auto step = [&](auto chk_c) __attribute__((always_inline)) {
+        constexpr bool CHK = decltype(chk_c)::value;
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
 #pragma unroll
         for (int cc = 0; cc < (TG_ABLATE == 2 ? 0 : MAXC); cc++) {
@@ -329,66 +348,129 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
         }
         __syncthreads();
         // -------------------------------------------------------- relaxation, projection, dual
+        if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; }
+        {
 #pragma unroll
-        for (int cc = 0; cc < (TG_ABLATE == 3 ? 0 : MAXC); cc++) {
-            const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
-            const double *xin = vx + i_var[cc];
-            const double *xpr = lds + i_prev[cc];
-            const double *ct = lds + i_ct[cc];
-            double xt[S], xp[S];
+            for (int cc = 0; cc < (TG_ABLATE == 3 ? 0 : MAXC); cc++) {
+                const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
+                const double *xin = vx + i_var[cc];
+                const double *xpr = lds + i_prev[cc];
+                const double *ct = lds + i_ct[cc];
+                double xt[S], xp[S];
 #pragma unroll
-            for (int k = 0; k < S; k++) { xt[k] = xin[k * 16]; xp[k] = xpr[k * 16]; }
-            // variables and their box rows
+                for (int k = 0; k < S; k++) { xt[k] = xin[k * 16]; xp[k] = xpr[k * 16]; }
+                // variables and their box rows
 #pragma unroll
-            for (int k = 0; k < S; k++) {
-                x[cc][k] = alpha * xt[k] + oma * x[cc][k];
-                const double zr = alpha * xt[k] + oma * zb[cc][k];
-                const double s = zr + yb[cc][k];
-                double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
-                if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
-                const double zn = clampd(s, lo, hi);
-                yb[cc][k] = s - zn;
-                zb[cc][k] = zn;
-            }
-            // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
+                for (int k = 0; k < S; k++) {
+                    x[cc][k] = alpha * xt[k] + oma * x[cc][k];
+                    const double zr = alpha * xt[k] + oma * zb[cc][k];
+                    const double s = zr + yb[cc][k];
+                    double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
+                    if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
+                    const double zn = clampd(s, lo, hi);
+                    if constexpr (CHK) {
+                        double d = ct[k * 3] * (zr - zn);
+                        if (hi > kInfBound) d = lo < -kInfBound ? 0.0 : fmin(d, 0.0);
+                        else if (lo < -kInfBound) d = fmax(d, 0.0);
+                        pin_n = fmax(pin_n, fabs(d));
+                        pin_l += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
+                        part[cc][k] = d;
+                    }
+                    yb[cc][k] = s - zn;
+                    zb[cc][k] = zn;
+                }
+                // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
 #pragma unroll
-            for (int k = 0; k < D; k++) {
-                double zt = -xt[k];
+                for (int k = 0; k < D; k++) {
+                    double zt = -xt[k];
 #pragma unroll
-                for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
-                if (k == D - 1) zt += dt * xp[D];
-                const double b = bg[cc][k];
-                const double zr = alpha * zt + oma * zg[cc][k];
-                const double s = zr + yg[cc][k];
-                yg[cc][k] = s - b;
-                zg[cc][k] = b;
-                lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
-            }
-            if (MIXED) {
-                if (mixrow[cc]) {
-                    // mixed rows of step st (mpc_12state.cpp:600-630), second axis read from LDS
-                    const double *yin = vx + i_oth[cc];
-                    const double vxx = xt[1], axx = xt[2], vyy = yin[16], ayy = yin[32];
-                    const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
-                                           -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+                    for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
+                    if (k == D - 1) zt += dt * xp[D];
+                    const double b = bg[cc][k];
+                    const double zr = alpha * zt + oma * zg[cc][k];
+                    const double s = zr + yg[cc][k];
+                    yg[cc][k] = s - b;
+                    zg[cc][k] = b;
+                    if constexpr (CHK) {
+                        const double d = rho_eq * (zr - b);
+                        pin_n = fmax(pin_n, fabs(d));
+                        pin_l += b * d;
+                        part[cc][k] -= d;
+                        lds[WEQ + (cw * D + k) * 16 + t] = d;
+                    } else {
+                        lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+                    }
+                }
+                if (MIXED) {
+                    if (mixrow[cc]) {
+                        // mixed rows of step st (mpc_12state.cpp:600-630), second axis read from LDS
+                        const double *yin = vx + i_oth[cc];
+                        const double vxx = xt[1], axx = xt[2], vyy = yin[16], ayy = yin[32];
+                        const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
+                                               -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
 #pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        const double zr = alpha * zt6[k] + oma * zm[cc][k];
-                        const double s = zr + ym[cc][k];
-                        const double zn = clampd(s, -ovm[cc][k], ovm[cc][k]);
-                        ym[cc][k] = s - zn;
-                        zm[cc][k] = zn;
-                        lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zn - ym[cc][k]);
+                        for (int k = 0; k < 6; k++) {
+                            const double zr = alpha * zt6[k] + oma * zm[cc][k];
+                            const double s = zr + ym[cc][k];
+                            const double zn = clampd(s, -ovm[cc][k], ovm[cc][k]);
+                            ym[cc][k] = s - zn;
+                            zm[cc][k] = zn;
+                            if constexpr (CHK) {
+                                double d = P.rho_mx[k] * (zr - zn);
+                                if (ovm[cc][k] > kInfBound) d = 0.0;
+                                pin_n = fmax(pin_n, fabs(d));
+                                pin_l += ovm[cc][k] * fabs(d);
+                                lds[i_mx[cc] + k * 16] = d;
+                            } else {
+                                lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zn - ym[cc][k]);
+                            }
+                        }
                     }
                 }
             }
         }
+    };
+
+    for (int iter = 0; iter < max_iter;) {
+        // iterations up to the next check: every `check` iterations and at max_iter
+        const int burst = min(check, max_iter - iter);
+        for (int i = 1; i < burst; i++) {
+            step(std::false_type{});
+            __syncthreads();
+        }
+        iter += burst;
+        step(std::true_type{});
         // -------------------------------------------------------- termination check
-        if (iter % check == 0 || iter == max_iter) {
+        {
+            __syncthreads();
+            // ||A' delta_y||_inf: own part + the next step's dynamics rows + the mixed rows
+            double m_atdy = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < MAXC; cc++) {
+                double dn[D], mixc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < D; k++) dn[k] = lds[i_wnext[cc] + k * 16];
+                if (MIXED) {
+                    const double *wm = lds + i_mx[cc];
+                    const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
+                    const double ca = axis0[cc] ? s3 : 0.5, cb = axis0[cc] ? 0.5 : s3, sg = axis0[cc] ? 1.0 : -1.0;
+                    mixc[1] = ca * (w0 + sg * w1) + cb * (w2 - sg * w3);
+                    mixc[2] = s2 * (w4 + sg * w5);
+                }
+#pragma unroll
+                for (int l = 0; l < D; l++) {
+                    double v = part[cc][l];
+#pragma unroll
+                    for (int k = 0; k <= l; k++) v += chain_coef<D>(k, l, dt, c2) * dn[k];
+                    if (MIXED && l >= 1) v += mixc[l];
+                    m_atdy = fmax(m_atdy, fabs(v));
+                }
+                m_atdy = fmax(m_atdy, fabs(part[cc][D] + dt * dn[D - 1]));
+            }
             __syncthreads();
             if (g == 0) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) red[k * 16 + t] = 0ull;
+                for (int k = 0; k < 9; k++) if (k != 6) red[k * 16 + t] = 0ull;
             }
             // x -> VX, y of the dynamics / mixed rows -> WEQ / WMX (restored below)
 #pragma unroll
@@ -493,12 +575,22 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             }
             m_rp = wave_gmax(m_rp); m_ax = wave_gmax(m_ax); m_z = wave_gmax(m_z);
             m_rd = wave_gmax(m_rd); m_px = wave_gmax(m_px); m_aty = wave_gmax(m_aty);
+            pin_n = wave_gmax(pin_n); m_atdy = wave_gmax(m_atdy);
+            pin_l += __shfl_xor(pin_l, 16);
+            pin_l += __shfl_xor(pin_l, 32);
             if ((lane >> 4) == 0) {
                 lds_max(&red[0 * 16 + t], m_rp); lds_max(&red[1 * 16 + t], m_ax);
                 lds_max(&red[2 * 16 + t], m_z);  lds_max(&red[3 * 16 + t], m_rd);
                 lds_max(&red[4 * 16 + t], m_px); lds_max(&red[5 * 16 + t], m_aty);
+                lds_max(&red[7 * 16 + t], pin_n); lds_max(&red[8 * 16 + t], m_atdy);
+                rsum[wave * 16 + t] = pin_l;
             }
             __syncthreads();
+            pin_n = __longlong_as_double((long long)red[7 * 16 + t]);
+            m_atdy = __longlong_as_double((long long)red[8 * 16 + t]);
+            pin_l = 0.0;
+#pragma unroll
+            for (int w = 0; w < kAdmmWaves; w++) pin_l += rsum[w * 16 + t];
             m_rp = __longlong_as_double((long long)red[0 * 16 + t]);
             m_ax = __longlong_as_double((long long)red[1 * 16 + t]);
             m_z = __longlong_as_double((long long)red[2 * 16 + t]);
@@ -508,10 +600,16 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             const double eps_p = P.eps_abs + P.eps_rel * fmax(m_ax, m_z);
             const double eps_d = P.eps_abs + P.eps_rel * fmax(fmax(m_px, m_aty), qn);
             const bool conv = (m_rp < eps_p) && (m_rd < eps_d);
-            if (!done && (conv || iter == max_iter)) {
+            // OSQP's certificate of primal infeasibility (is_primal_infeasible, only tried while
+            // the primal residual is above its tolerance): delta_y, projected on the polar of the
+            // recession cone of [l, u], separates the constraint set from the range of A
+            const bool pinf = !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
+                              pin_l < -eps_pinf * pin_n && m_atdy < eps_pinf * pin_n;
+            if (!done && (conv || pinf || iter == max_iter)) {
                 done = true;
-                // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551)
-                for (int cc = 0; cc < MAXC; cc++) {
+                // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
+                // is written for an infeasible instance
+                for (int cc = 0; cc < (conv || !pinf ? MAXC : 0); cc++) {
                     const int c = g + kCellStride * cc;
                     if (c < ncell) {
                         const int ax = c / N1, st = c - ax * N1;
@@ -522,7 +620,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
                     }
                 }
                 if (g == 0) {
-                    if (a.status) a.status[inst] = conv ? TG_DEV_SOLVED : TG_DEV_MAX_ITER;
+                    if (a.status) a.status[inst] = conv ? TG_DEV_SOLVED : (pinf ? TG_DEV_PRIMAL_INFEASIBLE : TG_DEV_MAX_ITER);
                     if (a.iters) a.iters[inst] = iter;
                     if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.ld + inst] = m_rd; }
                 }
@@ -663,7 +761,7 @@ size_t admm_lds_bytes(const StageDev &P)
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
                   (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8;
-    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + 7 * 16 * sizeof(double);
+    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + 8) * 16 * sizeof(double);
 }
 
 template <int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>

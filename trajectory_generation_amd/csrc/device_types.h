@@ -6,7 +6,9 @@ namespace tg {
 
 constexpr int kTileDev = 16;            // instances per workgroup = MFMA f64 16x16x4 columns
 constexpr double TG_DEV_INFTY = 1e30;   // OsqpEigen::INFTY
-constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2;
+constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2, TG_DEV_PRIMAL_INFEASIBLE = -3, TG_DEV_UNSOLVED = -10;
+constexpr double kInfBound = 1e26;      // OSQP_INFTY * MIN_SCALING: bounds beyond it count as infinite
+constexpr double kDivisionTol = 1e-30;  // 1 / OSQP_INFTY
 constexpr int kMaxAxes = 3, kMaxSlots = 4;
 constexpr int kAdmmThreads = 512, kAdmmWaves = kAdmmThreads / 64;   // ADMM workgroup
 constexpr int kCellStride = kAdmmThreads / kTileDev;                // cells g, g + 32, ... per thread
@@ -41,7 +43,7 @@ struct StageDev {
     int X_slot;                  // row distance between slots of one axis in X (6-DOF: 3, else 1)
     int x0_slot;                 // same for x0
     int U_stride, U_off[kMaxAxes];
-    double sigma, alpha, eps_abs, eps_rel;
+    double sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
     int max_iter, check;
 };
 
@@ -58,6 +60,7 @@ struct BatchArgs {
     const double *x0, *ref, *ov_box, *ov_mixed;
     double *X, *U;
     int *status, *iters;
+    const int *gate;         // optional: status of the upstream stage, instances != solved are skipped
     double *res;             // optional [2][ld]: primal / dual residual at exit
     int warm_in, warm_out;
     double *warm;            // [warm_rows][ldw] iterates kept between calls

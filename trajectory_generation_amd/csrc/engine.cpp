@@ -142,7 +142,7 @@ struct DevStage {
             size_t rows2 = (size_t)2 * sp.n_int + (size_t)ncell * sp.D + (dev.mixed ? (size_t)(mdl.N + 1) * 6 : 0);
             dev.separate_xt = rows2 * 16 * 8 + 1024 <= 80 * 1024 ? 1 : 0;
         }
-        dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel;
+        dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
         dev.max_iter = o.max_iter; dev.check = o.check_termination;
         adev.n = sp.n; adev.m = sp.m; adev.rows_per_block = 32;
         adev.q_w = d_qw; adev.l_t = d_lt; adev.u_t = d_ut; adev.q_ref_row = d_qrr;
@@ -247,7 +247,7 @@ static void from_soa(const std::vector<double> &soa, int B, int rows, int ld, do
 
 static int check_opts(const tg_solver_opts &o)
 {
-    if (!(o.sigma > 0) || !(o.alpha > 0 && o.alpha < 2) || !(o.eps_abs >= 0) || !(o.eps_rel >= 0) ||
+    if (!(o.sigma > 0) || !(o.alpha > 0 && o.alpha < 2) || !(o.eps_abs >= 0) || !(o.eps_rel >= 0) || !(o.eps_prim_inf >= 0) ||
         o.max_iter < 1 || o.check_termination < 1)
         return fail(TG_E_ARG, "invalid solver options");
     for (int k = 0; k < 4; k++)
@@ -260,7 +260,7 @@ extern "C" {
 void tg_default_opts(tg_solver_opts *o)
 {
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
-    o->max_iter = 4000; o->check_termination = 25;
+    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4;
     for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }
@@ -407,10 +407,13 @@ struct tg_mpc12 {
     {
         if (ld <= inter_ld) return TG_OK;
         hipFree(d_inter); d_inter = nullptr; inter_ld = 0;
-        HIP_TRY(hipMalloc((void **)&d_inter, (size_t)(13 * p.N + 1) * ld * sizeof(double)));
+        // + 2 rows holding the [3][ld] stage status used to gate the later stages when the
+        // caller passes no status array
+        HIP_TRY(hipMalloc((void **)&d_inter, (size_t)(13 * p.N + 1 + 2) * ld * sizeof(double)));
         inter_ld = ld;
         return TG_OK;
     }
+    int *own_status() { return (int *)(d_inter + (size_t)(13 * p.N + 1) * inter_ld); }
     double *xy_max() { return d_inter; }
     double *mixed_max() { return d_inter + (size_t)6 * p.N * inter_ld; }
     double *yaw_ref() { return d_inter + (size_t)12 * p.N * inter_ld; }
@@ -454,8 +457,11 @@ void tg_mpc12_destroy(tg_mpc12 *h)
     delete h;
 }
 
+// gated: instances whose upstream stage did not solve are skipped (status TG_UNSOLVED), as
+// MPC12STATE::mpcLoop returns at the first failing stage (mpc_12state.cpp:1374-1453)
 static int mpc12_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0, const double *d_ref,
-                       double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s)
+                       double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s,
+                       bool gated = false)
 {
     int rc = h->ensure_inter(ld);
     if (rc) return rc;
@@ -466,6 +472,7 @@ static int mpc12_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0
     const int slot = stage == TG_FAM_Z ? 0 : stage == TG_FAM_XY ? 1 : 2;
     a.status = d_status ? d_status + (size_t)slot * ld : nullptr;
     a.iters = d_iters ? d_iters + (size_t)slot * ld : nullptr;
+    if (gated && slot > 0 && d_status) a.gate = d_status + (size_t)(slot - 1) * ld;
     if (stage == TG_FAM_XY) {
         // computeXYBounds from the Z solution already in X, then updateXYQP + solve
         HIP_TRY(launch_xy_bounds(B, ld, p.N, p.xy_max_vel, p.xy_max_accel, p.z_max_accel, d_X,
@@ -498,9 +505,13 @@ int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const d
     // keep one leading dimension for the intermediates of a handle
     if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
     hipStream_t s = (hipStream_t)stream;
-    if ((rc = mpc12_stage(h, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s))) return rc;
-    if ((rc = mpc12_stage(h, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s))) return rc;
-    if ((rc = mpc12_stage(h, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s))) return rc;
+    if (!d_status) {
+        if ((rc = h->ensure_inter(ld))) return rc;
+        d_status = h->own_status();
+    }
+    if ((rc = mpc12_stage(h, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = mpc12_stage(h, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = mpc12_stage(h, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
     return TG_OK;
 }
 
