@@ -11,7 +11,7 @@ import sys
 
 
 def one_db(d):
-    f = glob.glob(os.path.join(d, "*.db"))
+    f = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
     return sqlite3.connect(f[0]) if f else None
 
 
@@ -20,7 +20,7 @@ def main(src, dst_prefix, workload):
     lines = []
     db = one_db(os.path.join(src, "trace"))
     if db:
-        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --no-cpu-baseline")
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 10 --no-cpu-baseline" % workload)
         lines.append("%-90s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
             lines.append("%-90s %8d %14.1f %12.2f %8.3f" % (name[:90], calls, total / 1e3 if total > 1e6 else total, avg / 1e3 if total > 1e6 else avg, pct))
@@ -56,6 +56,12 @@ def main(src, dst_prefix, workload):
         lines.append("HBM bytes per launch: raw %.0f, with the gfx950 FETCH_SIZE x2 correction %.0f" %
                      (raw + wr, 2 * raw + wr))
     os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
+    if "hbm_bytes_per_launch_fetch_x2" in out:
+        # per-workload HBM bytes per launch of the dominant kernel, read by bench.py ("traffic")
+        tf = os.path.join(os.path.dirname(dst_prefix), os.path.basename(dst_prefix).split("_")[0] + "_pmc_traffic.json")
+        cur = json.load(open(tf)) if os.path.exists(tf) else {}
+        cur[workload] = out["hbm_bytes_per_launch_fetch_x2"]
+        json.dump(cur, open(tf, "w"), indent=1)
     open(dst_prefix + "_rocprof_summary.txt", "w").write("\n".join(lines) + "\n")
     json.dump(out, open(dst_prefix + "_rocprof_summary.json", "w"), indent=1)
     print("\n".join(lines))

@@ -69,6 +69,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   WEQ w = rho z - y of the dynamics rows ncell*D + D rows
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
+//   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
 template <int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
 __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, const BatchArgs a)
 {
@@ -90,7 +91,8 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     const int WEQ = (P.separate_xt ? 2 : 1) * (n_int + S) * 16;
     const int WMX = WEQ + (ncell * D + D) * 16;
     const int ZERO = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);
-    const int CTAB = ZERO + 8 * 16;                                          // [NAX][S][3] rho, lb, ub
+    const int BGT = ZERO + 8 * 16;                                           // [NAX][D][16] -x0: l = u of the step-0 rows
+    const int CTAB = BGT + NAX * D * 16;                                     // [NAX][S][3] rho, lb, ub
     unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
     double *rsum = (double *)(red + 9 * 16);                                        // [8 waves][16] partial sums
     double *v0 = lds + V0, *vx = lds + VX;
@@ -110,7 +112,9 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
 
     // ------------------------------------------------------------ per-thread cell state
     double x[MAXC][S], zb[MAXC][S], yb[MAXC][S];   // variables and their identity box rows
-    double zg[MAXC][D], yg[MAXC][D], bg[MAXC][D];  // dynamics rows of the cell, their l = u
+    // dynamics rows of the cell: only y is kept.  Their z equals the bound b (l = u) after every
+    // projection, and b is -x0 at step 0 and zero elsewhere, so both are read through i_bg.
+    double yg[MAXC][D];
     double q[MAXC];                                // q of the position slot
     double hiv[MIXED ? MAXC : 1][2];               // XY: |v|, |a| box of the cell (per instance)
     double zm[MIXED ? MAXC : 1][6], ym[MIXED ? MAXC : 1][6], ovm[MIXED ? MAXC : 1][6];
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     int i_prev[MAXC];    // absolute index of the previous cell's variables in VX (or ZERO)
     int i_wnext[MAXC];   // absolute index of the next cell's dynamics-row w (or ZERO)
     int i_ct[MAXC];      // absolute index of the cell's axis in the constant table
+    int i_bg[MAXC];      // absolute index of the cell's dynamics-row bound (BGT at step 0, else ZERO)
     int i_mx[MIXED ? MAXC : 1];     // absolute index of the step's mixed-row w (or ZERO)
     int i_oth[MIXED ? MAXC : 1];    // XY: index of the other axis' cell of the same step, rel. to VX
     bool mixrow[MIXED ? MAXC : 1];  // this cell updates the mixed rows of its step
@@ -139,11 +144,13 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
         i_prev[cc] = (act && st > 0) ? VX + i_var[cc] - S * 16 : ZERO + t;
         i_wnext[cc] = (act && st < N) ? WEQ + ((c + 1) * D) * 16 + t : ZERO + t;
         i_ct[cc] = CTAB + ax * S * 3;
+        i_bg[cc] = (act && st == 0) ? BGT + ax * D * 16 + t : ZERO + t;
+        double zg0[D], b0[D];
         q[cc] = 0.0;
 #pragma unroll
         for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; yb[cc][k] = 0.0; }
 #pragma unroll
-        for (int k = 0; k < D; k++) { zg[cc][k] = 0.0; yg[cc][k] = 0.0; bg[cc][k] = 0.0; }
+        for (int k = 0; k < D; k++) { zg0[k] = 0.0; yg[cc][k] = 0.0; b0[k] = 0.0; }
         if (MIXED) {
             const int oth = ax == 0 ? P.axis_base[1] : P.axis_base[0];
             i_oth[cc] = act ? (oth + st * S) * 16 + t : n_int * 16 + t;
@@ -160,7 +167,10 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             qn = fmax(qn, fabs(q[cc]));
             if (st == 0) {
 #pragma unroll
-                for (int k = 0; k < D; k++) bg[cc][k] = -a.x0[(size_t)(x0r + k * P.x0_slot) * a.ld + inst];
+                for (int k = 0; k < D; k++) {
+                    b0[k] = -a.x0[(size_t)(x0r + k * P.x0_slot) * a.ld + inst];
+                    lds[i_bg[cc] + k * 16] = b0[k];
+                }
             }
             if (MIXED && st >= 1) {
                 const size_t r0 = (size_t)(6 * (st - 1) + 3 * ax) * a.ov_ld + inst;
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
                 const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
 #pragma unroll
                 for (int k = 0; k < D; k++) {
-                    zg[cc][k] = a.warm[e0 + (size_t)k * a.ldw];
+                    zg0[k] = a.warm[e0 + (size_t)k * a.ldw];
                     yg[cc][k] = a.warm[e0 + (size_t)(ncell * D + k) * a.ldw];
                 }
                 if (MIXED && ax == 0) {
@@ -198,7 +208,12 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
         // w of the cell's rows for the first rhs (unused slots write the spare rows at the end)
         const int cw = act ? c : ncell;
 #pragma unroll
-        for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
+        for (int k = 0; k < D; k++) {
+            lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg0[k] - yg[cc][k]);
+            // the first projection relaxes with the starting z (zero, or the previous solve's):
+            // alpha zt + (1-alpha) z0 + y = alpha zt + (1-alpha) b + [y + (1-alpha)(z0 - b)]
+            yg[cc][k] += oma * (zg0[k] - b0[k]);
+        }
         if (MIXED) {
             if (mixrow[cc]) {
 #pragma unroll
@@ -248,10 +263,9 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             double wn[D], wo[D];
 #pragma unroll
             for (int k = 0; k < D; k++) {
-                wo[k] = rho_eq * (zg[cc][k] - yg[cc][k]);
+                wo[k] = lds[WEQ + (cw * D + k) * 16 + t];
                 wn[k] = lds[i_wnext[cc] + k * 16];
             }
-            (void)cw;
             double mixc[3] = {0.0, 0.0, 0.0};
             if (MIXED) {
                 const double *wm = lds + i_mx[cc];
@@ -386,11 +400,10 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
 #pragma unroll
                     for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
                     if (k == D - 1) zt += dt * xp[D];
-                    const double b = bg[cc][k];
-                    const double zr = alpha * zt + oma * zg[cc][k];
+                    const double b = lds[i_bg[cc] + k * 16];
+                    const double zr = alpha * zt + oma * b;
                     const double s = zr + yg[cc][k];
                     yg[cc][k] = s - b;
-                    zg[cc][k] = b;
                     if constexpr (CHK) {
                         const double d = rho_eq * (zr - b);
                         pin_n = fmax(pin_n, fabs(d));
@@ -552,9 +565,10 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
 #pragma unroll
                         for (int l = k; l < D; l++) axv += chain_coef<D>(k, l, dt, c2) * xpr[l * 16];
                         if (k == D - 1) axv += dt * xpr[D * 16];
-                        m_rp = fmax(m_rp, fabs(axv - zg[cc][k]));
+                        const double b = lds[i_bg[cc] + k * 16];
+                        m_rp = fmax(m_rp, fabs(axv - b));
                         m_ax = fmax(m_ax, fabs(axv));
-                        m_z = fmax(m_z, fabs(zg[cc][k]));
+                        m_z = fmax(m_z, fabs(b));
                     }
                     // ... mixed rows
                     if (MIXED) {
@@ -643,7 +657,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
                             const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
 #pragma unroll
                             for (int k = 0; k < D; k++) {
-                                a.warm[e0 + (size_t)k * a.ldw] = zg[cc][k];
+                                a.warm[e0 + (size_t)k * a.ldw] = lds[i_bg[cc] + k * 16];
                                 a.warm[e0 + (size_t)(ncell * D + k) * a.ldw] = yg[cc][k];
                             }
                             if (MIXED && ax == 0) {
@@ -664,7 +678,8 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             for (int cc = 0; cc < MAXC; cc++) {
                 const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
 #pragma unroll
-                for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg[cc][k] - yg[cc][k]);
+                for (int k = 0; k < D; k++)
+                    lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (lds[i_bg[cc] + k * 16] - yg[cc][k]);
                 if (MIXED) {
                     if (mixrow[cc]) {
 #pragma unroll
@@ -760,7 +775,7 @@ size_t admm_lds_bytes(const StageDev &P)
 {
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
-                  (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8;
+                  (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D;
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + 8) * 16 * sizeof(double);
 }
 
