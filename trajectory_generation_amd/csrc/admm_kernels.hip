@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
 #pragma unroll
         for (int kk = 0; kk < KSREG; kk++) {
             const bool in = nit > 0 && kk < ks;
-            mreg[kk] = in ? P.Mfrag[((size_t)P.grp_op[grp] * nrb * ks + (size_t)rb * ks + kk) * 64 + lane] : 0.0;
+            mreg[kk] = in ? P.Mfrag[(((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc + kk) * 64 + lane] : 0.0;
         }
     }
 
@@ -246,6 +246,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     }
     const int max_iter = P.max_iter, check = P.check;
     const double eps_pinf = P.eps_prim_inf;
+    if (__syncthreads_and(done ? 1 : 0)) return;   // no instance of this tile is to be solved
 
     // One ADMM iteration.  CHK marks an iteration that is followed by a termination check: it
     // also needs the step delta_y = y+ - y of every row for OSQP's primal infeasibility test.
@@ -320,27 +321,49 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
                             }
                         }
                     } else {
-                        constexpr int PD = 8;   // k steps in flight
-                        const double *Mrow = P.Mfrag + ((size_t)P.grp_op[grp] * nrb + rb) * ks * 64 + lane;
-                        double af[PD];
+                        // ring of kRingDepth fragments in flight; the fragment array carries
+                        // kRingDepth zero steps of padding, so the prefetch needs no bounds test and
+                        // the loop body has no branches (a branch makes the compiler drain the ring)
+                        constexpr int PD = kRingDepth;
+                        const double *Mrow = P.Mfrag + ((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc * 64 + lane;
+                        auto run = [&](auto two_c) __attribute__((always_inline)) {
+                            constexpr bool TWO = decltype(two_c)::value;
+                            double af[PD];
 #pragma unroll
-                        for (int p = 0; p < PD; p++) af[p] = Mrow[(size_t)(p < ks ? p : ks - 1) * 64];
-                        for (int kk = 0; kk < ks; kk += PD) {
+                            for (int p = 0; p < PD; p++) af[p] = Mrow[p * 64];
+                            d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+                            const int full = ks / PD, rem = ks - full * PD;
+                            const double *mp = Mrow + PD * 64, *b0 = bp0, *b1 = bp1;
+                            for (int f = 0; f < full; f++) {
+#pragma unroll
+                                for (int p = 0; p < PD; p++) {
+                                    // the fragment's last use comes before its slot is reloaded, so
+                                    // the load can land in the same registers
+                                    const double bf0 = b0[p * 64];
+                                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                    if constexpr (TWO) {
+                                        const double bf1 = b1[p * 64];
+                                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
+                                    }
+                                    af[p] = mp[p * 64];
+                                }
+                                mp += PD * 64; b0 += PD * 64; b1 += PD * 64;
+                            }
 #pragma unroll
                             for (int p = 0; p < PD; p++) {
-                                const int k = kk + p;
-                                if (k < ks) {
-                                    const double bf0 = bp0[k * 64];
-                                    const double a_ = af[p];
-                                    af[p] = Mrow[(size_t)(k + PD < ks ? k + PD : k) * 64];
-                                    acc0[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf0, acc0[it], 0, 0, 0);
-                                    if (PAIR && two) {
-                                        const double bf1 = bp1[k * 64];
-                                        acc1[it] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_, bf1, acc1[it], 0, 0, 0);
+                                if (p < rem) {
+                                    const double bf0 = b0[p * 64];
+                                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                    if constexpr (TWO) {
+                                        const double bf1 = b1[p * 64];
+                                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
                                     }
                                 }
                             }
-                        }
+                            acc0[it] = c0;
+                            if constexpr (PAIR) acc1[it] = c1;
+                        };
+                        if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
                     }
                 }
             }

@@ -13,6 +13,7 @@ constexpr int kMaxAxes = 3, kMaxSlots = 4;
 constexpr int kAdmmThreads = 512, kAdmmWaves = kAdmmThreads / 64;   // ADMM workgroup
 constexpr int kCellStride = kAdmmThreads / kTileDev;                // cells g, g + 32, ... per thread
 constexpr int kMaxItems = 8;                                        // MFMA work items per wave
+constexpr int kRingDepth = 8;   // operator fragments (k steps) a wave keeps in flight from L2
 
 // One QP stage as the ADMM kernel sees it.  Every axis of the model is a chain of
 // integrators of order D (6-DOF: D = 2, states p,v, input a; 12-state stages: D = 3,
@@ -22,13 +23,14 @@ constexpr int kMaxItems = 8;                                        // MFMA work
 struct StageDev {
     int N, D, nax, mixed;        // horizon, chain order, axes, XY mixed rows present
     int n_int, nb, nrb, ks;      // padded size of all blocks, block size, row blocks, k steps
+    int ks_alloc;                // k steps stored per (operator, row block): ks + kRingDepth zero steps
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];
     int separate_xt;
     // MFMA work items (block group, row block) of every wave
     int wi_cnt[kAdmmWaves];
     unsigned char wi_grp[kAdmmWaves][kMaxItems], wi_rb[kAdmmWaves][kMaxItems];
-    const double *Mfrag;         // [nops][nrb][ks][64] operator fragments, MFMA A-operand order
+    const double *Mfrag;         // [nops][nrb][ks_alloc][64] operator fragments, MFMA A-operand order
     double dt, c2;               // c2 = dt^2/2 (position <- acceleration coupling, D = 3)
     double qw[kMaxAxes];         // q(position slot) = qw * ref            (qw = -state weight)
     double pdiag[kMaxAxes];      // P diagonal on the position slot

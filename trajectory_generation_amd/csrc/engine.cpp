@@ -87,7 +87,7 @@ struct DevStage {
         if ((rc = upload(sp.asm_ov_mixed, &d_ovm))) return rc;
         const bool six = mdl.family == TG_FAM_6DOF, xy = mdl.family == TG_FAM_XY;
         dev.N = mdl.N; dev.D = sp.D; dev.nax = sp.nax; dev.mixed = mdl.n_mixed ? 1 : 0;
-        dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = sp.nb / 16; dev.ks = sp.nb / 4;
+        dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = sp.nb / 16; dev.ks = sp.nb / 4; dev.ks_alloc = dev.ks + kRingDepth;
         // groups of up to two adjacent blocks that share an operator
         dev.ngrp = 0;
         for (int b = 0; b < sp.nblk;) {

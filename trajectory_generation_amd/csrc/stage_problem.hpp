@@ -60,7 +60,7 @@ struct StageProblem {
     int axis_base[kMaxAxes] = {0, 0, 0};
     std::vector<int> op_of_block;
     std::vector<int> var_ref;              // n_int -> reference variable or -1
-    std::vector<double> Mfrag;             // [nops][nb/16][nb/4][64]
+    std::vector<double> Mfrag;             // [nops][nb/16][nb/4 + kRingDepth][64]
     double rho_eq = 0;
     double rho_box[kMaxAxes][kMaxSlots] = {}, lb[kMaxAxes][kMaxSlots] = {}, ub[kMaxAxes][kMaxSlots] = {};
     double rho_mx[6] = {0}, ub_mx[6] = {0};
@@ -270,8 +270,8 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
     }
     sp.nops = (int)op_rep.size();
     // operator fragments: Mfrag[op][rb][kk][lane] = Kinv_block[rb*16 + (lane&15)][4*kk + (lane>>4)]
-    const int nrb = sp.nb / 16, ks = sp.nb / 4;
-    sp.Mfrag.assign((size_t)sp.nops * nrb * ks * 64, 0.0);
+    const int nrb = sp.nb / 16, ks = sp.nb / 4, ksa = ks + kRingDepth;   // zero steps: prefetch overrun
+    sp.Mfrag.assign((size_t)sp.nops * nrb * ksa * 64, 0.0);
     for (int o = 0; o < sp.nops; o++) {
         const int b = op_rep[o];
         for (int rb = 0; rb < nrb; rb++)
@@ -279,7 +279,7 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
                 for (int lane = 0; lane < 64; lane++) {
                     int ri = sp.var_ref[b * sp.nb + rb * 16 + (lane & 15)], rk = sp.var_ref[b * sp.nb + 4 * kk + (lane >> 4)];
                     double v = (ri >= 0 && rk >= 0) ? sp.Kinv[(size_t)ri * n + rk] : 0.0;
-                    sp.Mfrag[(((size_t)o * nrb + rb) * ks + kk) * 64 + lane] = v;
+                    sp.Mfrag[(((size_t)o * nrb + rb) * ksa + kk) * 64 + lane] = v;
                 }
     }
     // per-axis, per-slot step sizes and box templates (identical at every step)
