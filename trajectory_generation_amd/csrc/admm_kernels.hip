@@ -57,8 +57,9 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
     return d == 0 ? 1.0 : (d == 1 ? dt : c2);
 }
 
-// A workgroup is 8 waves (512 threads): thread (g = tid / 16, t = tid % 16) owns the cells
-// g, g + 32, ... of instance t.  The MFMA work is cut into items (block group, row block)
+// A workgroup is NT threads (8 or 4 waves): thread (g = tid / 16, t = tid % 16) owns the cells
+// g, g + NT/16, ... of instance t.  With 4 waves two workgroups share a CU and the hardware
+// overlaps the MFMA phase of one with the projection phase of the other.  The MFMA work is cut into items (block group, row block)
 // dealt to the waves by the host (StageDev::wi_*), at most MAXIT per wave.
 // KSREG > 0: the operator fragments of the wave's single item stay in registers for the whole
 // solve (needs MAXIT == 1 and ks <= KSREG); KSREG == 0: they are streamed from L2.
@@ -70,10 +71,11 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
 //   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
-template <int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
-__global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, const BatchArgs a)
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
+__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
+    constexpr int kThreads = NT, kWaves = NT / 64, kStride = NT / kTileDev;
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int t = tid & 15, g = tid >> 4;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     const double dt = P.dt, c2 = P.c2, rho_eq = P.rho_eq;
     constexpr double s3 = 0.86602540378443864676, s2 = 0.70710678118654752440; // sqrt(3)/2, sqrt(2)/2
 
-    for (int j = tid; j < CTAB; j += kAdmmThreads) lds[j] = 0.0;
+    for (int j = tid; j < CTAB; j += kThreads) lds[j] = 0.0;
     if (tid < NAX * S) {
         const int ax = tid / S, k = tid % S;
         lds[CTAB + tid * 3 + 0] = P.rho_box[ax][k];
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
     double qn = 0.0;
 #pragma unroll
     for (int cc = 0; cc < MAXC; cc++) {
-        const int c = g + kCellStride * cc;
+        const int c = g + kStride * cc;
         const bool act = c < ncell;
         const int ax = act ? c / N1 : 0;
         const int st = act ? c - ax * N1 : 0;
@@ -260,7 +262,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
 #pragma unroll
         for (int cc = 0; cc < (TG_ABLATE == 2 ? 0 : MAXC); cc++) {
-            const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
+            const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
             double wn[D], wo[D];
 #pragma unroll
             for (int k = 0; k < D; k++) {
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
         {
 #pragma unroll
             for (int cc = 0; cc < (TG_ABLATE == 3 ? 0 : MAXC); cc++) {
-                const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
+                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
                 const double *xin = vx + i_var[cc];
                 const double *xpr = lds + i_prev[cc];
                 const double *ct = lds + i_ct[cc];
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             // x -> VX, y of the dynamics / mixed rows -> WEQ / WMX (restored below)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
+                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
                 double *xo = vx + i_var[cc];
 #pragma unroll
                 for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int c = g + kCellStride * cc;
+                const int c = g + kStride * cc;
                 if (c < ncell) {
                     const int ax = c / N1, st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
@@ -627,7 +629,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             m_atdy = __longlong_as_double((long long)red[8 * 16 + t]);
             pin_l = 0.0;
 #pragma unroll
-            for (int w = 0; w < kAdmmWaves; w++) pin_l += rsum[w * 16 + t];
+            for (int w = 0; w < kWaves; w++) pin_l += rsum[w * 16 + t];
             m_rp = __longlong_as_double((long long)red[0 * 16 + t]);
             m_ax = __longlong_as_double((long long)red[1 * 16 + t]);
             m_z = __longlong_as_double((long long)red[2 * 16 + t]);
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
                 // is written for an infeasible instance
                 for (int cc = 0; cc < (conv || !pinf ? MAXC : 0); cc++) {
-                    const int c = g + kCellStride * cc;
+                    const int c = g + kStride * cc;
                     if (c < ncell) {
                         const int ax = c / N1, st = c - ax * N1;
                         const double *xs = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
@@ -664,7 +666,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
                 if (a.warm_out) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
-                        const int c = g + kCellStride * cc;
+                        const int c = g + kStride * cc;
                         if (c < ncell) {
                             const int ax = c / N1, st = c - ax * N1;
                             int abase = 0;
@@ -699,7 +701,7 @@ __global__ __launch_bounds__(kAdmmThreads) void admm_kernel(const StageDev P, co
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = (g + kCellStride * cc) < ncell ? g + kCellStride * cc : ncell;
+                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
 #pragma unroll
                 for (int k = 0; k < D; k++)
                     lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (lds[i_bg[cc] + k * 16] - yg[cc][k]);
@@ -802,35 +804,37 @@ size_t admm_lds_bytes(const StageDev &P)
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + 8) * 16 * sizeof(double);
 }
 
-template <int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG>;
     const size_t lds_bytes = admm_lds_bytes(P);
     hipError_t e = hipFuncSetAttribute((const void *)kern,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     const int grid = (a.B + kTileDev - 1) / kTileDev;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kAdmmThreads), lds_bytes, s, P, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, s, P, a);
     return hipGetLastError();
 }
 
 hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why)
 {
     const int ncell = P.nax * (P.N + 1);
-    const int needc = (ncell + kCellStride - 1) / kCellStride;
+    const int stride = P.nwaves * 64 / kTileDev;
+    const int needc = (ncell + stride - 1) / stride;
     int needi = 0;
-    for (int w = 0; w < kAdmmWaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
+    for (int w = 0; w < P.nwaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
     if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
+    if (P.nwaves != 8) { *why = "only 8-wave workgroups are compiled"; return hipErrorInvalidValue; }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (needc <= 2 && needi <= 1 && P.ks <= 16) return launch_admm_t<2, 3, false, 2, 1, true, 16>(P, a, s);
-        if (needc <= 5 && needi <= 3) return launch_admm_t<2, 3, false, 5, 3, true, 0>(P, a, s);
+        if (needc <= 2 && needi <= 1 && P.ks <= 16) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16>(P, a, s);
+        if (needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
-        if (needc <= 2 && needi <= 2) return launch_admm_t<3, 2, true, 2, 2, false, 0>(P, a, s);
-        if (needc <= 4 && needi <= 4) return launch_admm_t<3, 2, true, 4, 4, false, 0>(P, a, s);
+        if (needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0>(P, a, s);
+        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (needc <= 1 && needi <= 1 && P.ks <= 24) return launch_admm_t<3, 1, false, 1, 1, false, 24>(P, a, s);
-        if (needc <= 2 && needi <= 2) return launch_admm_t<3, 1, false, 2, 2, false, 0>(P, a, s);
+        if (needc <= 1 && needi <= 1 && P.ks <= 24) return launch_admm_t<512, 3, 1, false, 1, 1, false, 24>(P, a, s);
+        if (needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0>(P, a, s);
     }
     *why = "horizon too long for the compiled kernel variants";
     return hipErrorInvalidValue;

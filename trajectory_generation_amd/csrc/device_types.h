@@ -10,8 +10,7 @@ constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2, TG_DEV_PRIMAL_INFEASIBLE 
 constexpr double kInfBound = 1e26;      // OSQP_INFTY * MIN_SCALING: bounds beyond it count as infinite
 constexpr double kDivisionTol = 1e-30;  // 1 / OSQP_INFTY
 constexpr int kMaxAxes = 3, kMaxSlots = 4;
-constexpr int kAdmmThreads = 512, kAdmmWaves = kAdmmThreads / 64;   // ADMM workgroup
-constexpr int kCellStride = kAdmmThreads / kTileDev;                // cells g, g + 32, ... per thread
+constexpr int kAdmmWaves = 8;           // most waves an ADMM workgroup has (StageDev::nwaves: 4 or 8)
 constexpr int kMaxItems = 8;                                        // MFMA work items per wave
 constexpr int kRingDepth = 8;   // operator fragments (k steps) a wave keeps in flight from L2
 
@@ -27,6 +26,7 @@ struct StageDev {
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];
     int separate_xt;
+    int nwaves;                  // waves per workgroup the MFMA items are dealt to
     // MFMA work items (block group, row block) of every wave
     int wi_cnt[kAdmmWaves];
     unsigned char wi_grp[kAdmmWaves][kMaxItems], wi_rb[kAdmmWaves][kMaxItems];

@@ -88,6 +88,7 @@ struct DevStage {
         const bool six = mdl.family == TG_FAM_6DOF, xy = mdl.family == TG_FAM_XY;
         dev.N = mdl.N; dev.D = sp.D; dev.nax = sp.nax; dev.mixed = mdl.n_mixed ? 1 : 0;
         dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = sp.nb / 16; dev.ks = sp.nb / 4; dev.ks_alloc = dev.ks + kRingDepth;
+        dev.nwaves = 8;
         // groups of up to two adjacent blocks that share an operator
         dev.ngrp = 0;
         for (int b = 0; b < sp.nblk;) {
@@ -108,7 +109,7 @@ struct DevStage {
             for (const Item &it : items) {
                 int sd = 0;
                 for (int k = 1; k < 4; k++) if (simd_load[k] < simd_load[sd]) sd = k;
-                int w = wave_load[sd] <= wave_load[sd + 4] ? sd : sd + 4;
+                int w = (dev.nwaves == 4 || wave_load[sd] <= wave_load[sd + 4]) ? sd : sd + 4;
                 if (dev.wi_cnt[w] >= kMaxItems) return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
                 dev.wi_grp[w][dev.wi_cnt[w]] = (unsigned char)it.grp;
                 dev.wi_rb[w][dev.wi_cnt[w]] = (unsigned char)it.rb;
