@@ -138,6 +138,20 @@ def main():
     kern_ms, kern_launches = tg.timing_read(reset=True)
     tg.timing_enable(False)
 
+    # the same step when the boundary hands over host buffers: H2D of x0 / ref (pinned, SoA),
+    # solve, D2H of X / U / status; reported beside the resident-in-HBM figure, never as `value`
+    hx0 = buf["x0"].cpu().pin_memory(); href = buf["ref"].cpu().pin_memory()
+    hX = torch.empty_like(buf["X"], device="cpu").pin_memory(); hU = torch.empty_like(buf["U"], device="cpu").pin_memory()
+    hst = torch.empty_like(buf["status"], device="cpu").pin_memory()
+    pcie = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        buf["x0"].copy_(hx0, non_blocking=True); buf["ref"].copy_(href, non_blocking=True)
+        eng.solve(buf)
+        hX.copy_(buf["X"], non_blocking=True); hU.copy_(buf["U"], non_blocking=True); hst.copy_(buf["status"], non_blocking=True)
+        torch.cuda.synchronize(); pcie.append(time.perf_counter() - t1)
+    pcie_rate = B / float(np.median(pcie))
+
     iters = buf["iters"].cpu().numpy().reshape(-1, buf["ld"])[:, :B]
     status = buf["status"].cpu().numpy().reshape(-1, buf["ld"])[:, :B]
     stats = torch.tensor([float(iters.sum()), float((status == 1).all(0).sum()), float(B)],
@@ -180,6 +194,8 @@ def main():
         "p50_batch_ms": float(np.median(lat)),
         "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),
         "solved_frac": float(stats[1].item()) / total_inst,
+        "iters_hist": {str(int(k)): int(v) for k, v in zip(*np.unique(iters, return_counts=True))},
+        "pcie_inclusive_solves_per_s_rank0": pcie_rate,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "admm_kernel",
                      "avg_kernel_ms": avg_kernel_ms, "launches_timed": kern_launches,

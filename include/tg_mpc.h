@@ -118,6 +118,12 @@ int tg_mpc6_solve_host(tg_mpc6 *h, int B, const double *x0, const double *ref, d
 int tg_mpc6_assemble_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const double *d_ref,
                            double *d_q, double *d_l, double *d_u, void *stream);
 
+/* same on host vectors, instance-major (q[B][n], l[B][m], u[B][m]; any output may be NULL):
+ * what getGradient / getLowerBounds / getUpperBounds (mpc_6dof.cpp:859-873) return after
+ * updateQP for the given x0 and reference */
+int tg_mpc6_assemble_host(tg_mpc6 *h, int B, const double *x0, const double *ref, double *q,
+                          double *l, double *u);
+
 /* drop the stored warm-start iterates */
 int tg_mpc6_reset_warm(tg_mpc6 *h);
 /* getters of the reference (getHessianMatrix, getContraintsMatrix, getTransitionMatrix,
@@ -162,6 +168,9 @@ int tg_mpc12_intermediates(tg_mpc12 *h, const double **d_xy_max, const double **
 int tg_mpc12_assemble_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0,
                             const double *d_ref, const double *d_X, double *d_q, double *d_l,
                             double *d_u, void *stream);
+/* host vectors, instance-major; X (the upstream solution, [B][12(N+1)]) may be NULL for Z */
+int tg_mpc12_assemble_host(tg_mpc12 *h, int stage, int B, const double *x0, const double *ref,
+                           const double *X, double *q, double *l, double *u);
 int tg_mpc12_reset_warm(tg_mpc12 *h);
 int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m);
 int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out);

@@ -55,6 +55,7 @@ SYMBOLS = {
     "tg_mpc6_solve_batch": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _i, _vp]),
     "tg_mpc6_solve_host": (_i, [_vp, _i, _dp, _dp, _dp, _dp, _ip, _ip, _i]),
     "tg_mpc6_assemble_batch": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _dp, _vp]),
+    "tg_mpc6_assemble_host": (_i, [_vp, _i, _dp, _dp, _dp, _dp, _dp]),
     "tg_mpc6_reset_warm": (_i, [_vp]),
     "tg_mpc6_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc6_get": (_i, [_vp, _i, _dp]),
@@ -66,6 +67,7 @@ SYMBOLS = {
     "tg_mpc12_solve_stage": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _vp]),
     "tg_mpc12_intermediates": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i)]),
     "tg_mpc12_assemble_stage": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _vp]),
+    "tg_mpc12_assemble_host": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp]),
     "tg_mpc12_reset_warm": (_i, [_vp]),
     "tg_mpc12_dims": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc12_get": (_i, [_vp, _i, _i, _dp]),

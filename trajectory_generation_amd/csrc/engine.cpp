@@ -383,6 +383,38 @@ int tg_mpc6_assemble_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const 
     return TG_OK;
 }
 
+int tg_mpc6_assemble_host(tg_mpc6 *h, int B, const double *x0, const double *ref, double *q, double *l, double *u)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0) return fail(TG_E_ARG, "B < 0");
+    if (B == 0) return TG_OK;
+    if (!x0 || !ref) return fail(TG_E_ARG, "null host array");
+    if ((l == nullptr) != (u == nullptr)) return fail(TG_E_ARG, "l and u go together");
+    HIP_TRY(hipSetDevice(h->device));
+    const int N = h->p.N, ld = (B + 15) / 16 * 16, n = h->st.sp.n, m = h->st.sp.m;
+    const int rx = 6, rr = 6 * (N + 1);
+    int rc = h->hs.ensure((size_t)(rx + rr + n + 2 * m) * ld, 0);
+    if (rc) return rc;
+    double *dx0 = h->hs.d, *dref = dx0 + (size_t)rx * ld, *dq = dref + (size_t)rr * ld;
+    double *dl = dq + (size_t)n * ld, *du = dl + (size_t)m * ld;
+    std::vector<double> tmp;
+    to_soa(x0, B, rx, ld, tmp);
+    HIP_TRY(hipMemcpy(dx0, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    to_soa(ref, B, rr, ld, tmp);
+    HIP_TRY(hipMemcpy(dref, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    rc = tg_mpc6_assemble_batch(h, B, ld, dx0, dref, q ? dq : nullptr, l ? dl : nullptr, u ? du : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    struct Out { double *host; double *dev; int rows; } outs[3] = {{q, dq, n}, {l, dl, m}, {u, du, m}};
+    for (const Out &o : outs) {
+        if (!o.host) continue;
+        tmp.resize((size_t)o.rows * ld);
+        HIP_TRY(hipMemcpy(tmp.data(), o.dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        from_soa(tmp, B, o.rows, ld, o.host);
+    }
+    return TG_OK;
+}
+
 int tg_mpc6_reset_warm(tg_mpc6 *h) { if (!h) return fail(TG_E_ARG, "null handle"); h->st.warm_valid = false; return TG_OK; }
 int tg_mpc6_dims(const tg_mpc6 *h, int *n, int *m)
 {
@@ -604,6 +636,46 @@ int tg_mpc12_assemble_stage(tg_mpc12 *h, int stage, int B, int ld, const double 
         a.ref = h->yaw_ref(); a.ref_ld = h->inter_ld;
     }
     HIP_TRY(launch_assemble(h->st[stage].adev, a, d_q, d_l, d_u, s));
+    return TG_OK;
+}
+
+int tg_mpc12_assemble_host(tg_mpc12 *h, int stage, int B, const double *x0, const double *ref, const double *X,
+                           double *q, double *l, double *u)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0) return fail(TG_E_ARG, "B < 0");
+    if (B == 0) return TG_OK;
+    if (stage < TG_FAM_XY || stage > TG_FAM_YAW) return fail(TG_E_ARG, "stage must be XY, Z or YAW");
+    if (!x0 || !ref) return fail(TG_E_ARG, "null host array");
+    if (stage != TG_FAM_Z && !X) return fail(TG_E_ARG, "XY / Yaw assembly needs the upstream solution in X");
+    if ((l == nullptr) != (u == nullptr)) return fail(TG_E_ARG, "l and u go together");
+    HIP_TRY(hipSetDevice(h->device));
+    const int N = h->p.N, ld = (B + 15) / 16 * 16, n = h->st[stage].sp.n, m = h->st[stage].sp.m;
+    const int rx = 12, rr = 12 * (N + 1);
+    int rc = h->hs.ensure((size_t)(rx + 2 * rr + n + 2 * m) * ld, (size_t)6 * ld);
+    if (rc) return rc;
+    double *dx0 = h->hs.d, *dref = dx0 + (size_t)rx * ld, *dX = dref + (size_t)rr * ld, *dq = dX + (size_t)rr * ld;
+    double *dl = dq + (size_t)n * ld, *du = dl + (size_t)m * ld;
+    std::vector<double> tmp;
+    to_soa(x0, B, rx, ld, tmp);
+    HIP_TRY(hipMemcpy(dx0, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    to_soa(ref, B, rr, ld, tmp);
+    HIP_TRY(hipMemcpy(dref, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    if (X) {
+        to_soa(X, B, rr, ld, tmp);
+        HIP_TRY(hipMemcpy(dX, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    rc = tg_mpc12_assemble_stage(h, stage, B, ld, dx0, dref, X ? dX : nullptr, q ? dq : nullptr,
+                                 l ? dl : nullptr, u ? du : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    struct Out { double *host; double *dev; int rows; } outs[3] = {{q, dq, n}, {l, dl, m}, {u, du, m}};
+    for (const Out &o : outs) {
+        if (!o.host) continue;
+        tmp.resize((size_t)o.rows * ld);
+        HIP_TRY(hipMemcpy(tmp.data(), o.dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        from_soa(tmp, B, o.rows, ld, o.host);
+    }
     return TG_OK;
 }
 
