@@ -26,6 +26,9 @@ WORKLOADS = {
     "mpc_6dof_B4096_N20": ("6dof", 4096, 20, 2),
     "mpc_12state_B4096_N20": ("12state", 4096, 20, 3),
     "mpc_6dof_B32768_N50": ("6dof", 32768, 50, 4),
+    # closed loop (BASELINE.json configs[4]): a step = warm-started solve + plant update + reference shift
+    "rollout_12state_B8192_N20": ("12state", 8192, 20, 5),
+    "rollout_6dof_B8192_N20": ("6dof", 8192, 20, 5),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD)
 
@@ -82,6 +85,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="mpc_6dof_B4096_N20", choices=sorted(WORKLOADS))
     ap.add_argument("--eps", type=float, default=1e-3)
+    ap.add_argument("--max-iter", type=int, default=4000, help="ADMM iteration budget per solve (OSQP default 4000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,7 +102,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     model, B, N, seed_off = WORKLOADS[args.workload]
-    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps)
+    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter)
     first = rank * B                       # weak scaling: every rank owns its own slab of B instances
     if model == "6dof":
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts, device=local)
@@ -114,12 +118,22 @@ def main():
         if world > 1:
             dist.barrier()
 
+    closed = args.workload.startswith("rollout")
+
+    def step():
+        if closed:
+            eng.solve(buf, warm=True)
+            eng.plant_step(buf)
+            eng.ref_shift(buf)
+        else:
+            eng.solve(buf)
+
     for _ in range(args.warmup):
-        eng.solve(buf)
+        step()
     torch.cuda.synchronize(); barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.solve(buf)
+        step()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -133,7 +147,7 @@ def main():
     tg.timing_enable(True); tg.timing_read(reset=True)
     for _ in range(max(5, min(args.steps, 20))):
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        eng.solve(buf)
+        step()
         torch.cuda.synchronize(); lat.append((time.perf_counter() - t1) * 1e3)
     kern_ms, kern_launches = tg.timing_read(reset=True)
     tg.timing_enable(False)
@@ -147,7 +161,7 @@ def main():
     for _ in range(5):
         torch.cuda.synchronize(); t1 = time.perf_counter()
         buf["x0"].copy_(hx0, non_blocking=True); buf["ref"].copy_(href, non_blocking=True)
-        eng.solve(buf)
+        eng.solve(buf, warm=closed)
         hX.copy_(buf["X"], non_blocking=True); hU.copy_(buf["U"], non_blocking=True); hst.copy_(buf["status"], non_blocking=True)
         torch.cuda.synchronize(); pcie.append(time.perf_counter() - t1)
     pcie_rate = B / float(np.median(pcie))
@@ -189,7 +203,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "model": None, "instances_per_gpu": B, "horizon_N": N,
-                   "eps_abs": args.eps, "eps_rel": args.eps, "rho": eng.rho if model == "6dof" else
+                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "rho": eng.rho if model == "6dof" else
                    [eng.rho(k) for k in ("xy", "z", "yaw")], "parallelism": "instances sharded x%d" % world},
         "p50_batch_ms": float(np.median(lat)),
         "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),
@@ -204,6 +218,9 @@ def main():
     del out["config"]["model"]
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(model, N, seed_off, args.eps, out["config"]["rho"], eng.rho_rows())
+        if closed:
+            out["cpu_baseline"]["sample"] += "; cold-started single solves of the same problems (the closed-loop GPU " \
+                                             "steps are warm-started)"
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

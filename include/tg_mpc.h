@@ -176,6 +176,18 @@ int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m);
 int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out);
 double tg_mpc12_rho(const tg_mpc12 *h, int stage);
 
+/* ------------------------------------------------------------------ closed-loop roll-out */
+/* Plant update with the first control of the horizon, x0 <- A x0 + B u(0), A and B being
+ * getTransitionMatrix / getInputMatrix: the rule both test mains roll the solution out with
+ * (test_mpc_6dof.cpp:115-122, test_mpc_12state.cpp:193-197; mpc_12state.cpp:2001-2025).
+ * d_x0 [nx][ld] is updated in place, d_U is the U array of the last solve (rows 0..nu-1 used). */
+int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, const double *d_U, void *stream);
+int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, const double *d_U, void *stream);
+/* Receding horizon on a reference array ref [nx(N+1)][ld]: block i+1 moves to block i, the last
+ * block is continued linearly.  What mpc_ros.cpp / mpc_12state_ros.cpp get from their reference
+ * topic at every step, produced on the device. */
+int tg_ref_shift(int B, int ld, int nx, int N, double *d_ref, void *stream);
+
 /* device -> host copy of `bytes` bytes on the current device (for callers without a HIP
  * runtime of their own, e.g. a ctypes binding reading tg_mpc12_intermediates) */
 int tg_copy_to_host(void *dst, const void *d_src, unsigned long long bytes);

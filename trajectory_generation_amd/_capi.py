@@ -72,6 +72,9 @@ SYMBOLS = {
     "tg_mpc12_dims": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc12_get": (_i, [_vp, _i, _i, _dp]),
     "tg_mpc12_rho": (_d, [_vp, _i]),
+    "tg_mpc6_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _vp]),
+    "tg_mpc12_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _vp]),
+    "tg_ref_shift": (_i, [_i, _i, _i, _i, _dp, _vp]),
     "tg_copy_to_host": (_i, [_vp, _vp, C.c_ulonglong]),
     "tg_timing_enable": (None, [_i]),
     "tg_timing_read": (_i, [C.POINTER(_d), C.POINTER(_i), C.POINTER(_d), _i]),

@@ -795,6 +795,51 @@ __global__ __launch_bounds__(256) void yaw_ref_kernel(int B, int ld, int N,
     yaw_ref[(size_t)i * ld + inst] = atan2(yt - yi, xt - xi);
 }
 
+// ---------------------------------------------------------------- closed-loop roll-out helpers
+// Plant update with the first control of the horizon, x0 <- A x0 + B u(0): the rule the reference's
+// test mains roll the solution out with (test_mpc_6dof.cpp:115-122, test_mpc_12state.cpp:193-197).
+struct PlantDev {
+    int nx, nu;
+    double A[12 * 12], Bm[12 * 4];   // row-major, model-level (12-state: block diagonal)
+};
+
+__global__ __launch_bounds__(256) void plant_step_kernel(const PlantDev P, int B, int ld,
+                                                          double *__restrict__ x0,
+                                                          const double *__restrict__ U)
+{
+#pragma clang fp contract(off)
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= B) return;
+    double x[12], u[4], y[12];
+    for (int c = 0; c < P.nx; c++) x[c] = x0[(size_t)c * ld + inst];
+    for (int k = 0; k < P.nu; k++) u[k] = U[(size_t)k * ld + inst];
+    for (int r = 0; r < P.nx; r++) {
+        double s = 0.0;
+        for (int c = 0; c < P.nx; c++) s += P.A[r * P.nx + c] * x[c];
+        for (int k = 0; k < P.nu; k++) s += P.Bm[r * P.nu + k] * u[k];
+        y[r] = s;
+    }
+    for (int r = 0; r < P.nx; r++) x0[(size_t)r * ld + inst] = y[r];
+}
+
+// Receding horizon: the reference block of step i+1 moves to step i; the last block is continued
+// linearly (ref(N) + (ref(N) - ref(N-1))), which is exact for the constant-velocity references of
+// the synthetic workloads.  One thread per (state component, instance).
+__global__ __launch_bounds__(256) void ref_shift_kernel(int B, int ld, int nx, int N, double *__restrict__ ref)
+{
+#pragma clang fp contract(off)
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    const int a = blockIdx.y;
+    if (inst >= B || a >= nx) return;
+    double prev = ref[(size_t)a * ld + inst], cur = prev;
+    for (int i = 0; i < N; i++) {
+        prev = cur;
+        cur = ref[(size_t)((i + 1) * nx + a) * ld + inst];
+        ref[(size_t)(i * nx + a) * ld + inst] = cur;
+    }
+    if (N >= 1) ref[(size_t)(N * nx + a) * ld + inst] = cur + (cur - prev);
+}
+
 // ---------------------------------------------------------------- host-callable launchers
 size_t admm_lds_bytes(const StageDev &P)
 {
@@ -864,6 +909,23 @@ hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double 
 {
     dim3 grid((B + 255) / 256, N + 1);
     hipLaunchKernelGGL(yaw_ref_kernel, grid, dim3(256), 0, s, B, ld, N, ref, X, yaw_ref);
+    return hipGetLastError();
+}
+
+hipError_t launch_plant_step(int nx, int nu, const double *A, const double *Bm, int B, int ld, double *x0,
+                             const double *U, hipStream_t s)
+{
+    PlantDev P{};
+    P.nx = nx; P.nu = nu;
+    for (int i = 0; i < nx * nx; i++) P.A[i] = A[i];
+    for (int i = 0; i < nx * nu; i++) P.Bm[i] = Bm[i];
+    hipLaunchKernelGGL(plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, s, P, B, ld, x0, U);
+    return hipGetLastError();
+}
+
+hipError_t launch_ref_shift(int B, int ld, int nx, int N, double *ref, hipStream_t s)
+{
+    hipLaunchKernelGGL(ref_shift_kernel, dim3((B + 255) / 256, nx), dim3(256), 0, s, B, ld, nx, N, ref);
     return hipGetLastError();
 }
 

@@ -17,6 +17,9 @@ hipError_t launch_assemble(const AsmDev &P, const BatchArgs &a, double *q, doubl
 hipError_t launch_xy_bounds(int B, int ld, int N, double xy_max_vel, double xy_max_accel,
                             double z_max_accel, const double *X, double *xy_max, double *mixed_max,
                             hipStream_t s);
+hipError_t launch_plant_step(int nx, int nu, const double *A, const double *Bm, int B, int ld, double *x0,
+                             const double *U, hipStream_t s);
+hipError_t launch_ref_shift(int B, int ld, int nx, int N, double *ref, hipStream_t s);
 hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
                           hipStream_t s);
 } // namespace tg
@@ -415,6 +418,26 @@ int tg_mpc6_assemble_host(tg_mpc6 *h, int B, const double *x0, const double *ref
     return TG_OK;
 }
 
+int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, const double *d_U, void *stream)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
+    if (B == 0) return TG_OK;
+    if (!d_x0 || !d_U) return fail(TG_E_ARG, "null device array");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(launch_plant_step(6, 3, h->st.sp.mdl.Ad, h->st.sp.mdl.Bd, B, ld, d_x0, d_U, (hipStream_t)stream));
+    return TG_OK;
+}
+
+int tg_ref_shift(int B, int ld, int nx, int N, double *d_ref, void *stream)
+{
+    if (B < 0 || ld < B || nx < 1 || nx > 12 || N < 1) return fail(TG_E_ARG, "bad argument");
+    if (B == 0) return TG_OK;
+    if (!d_ref) return fail(TG_E_ARG, "null device array");
+    HIP_TRY(launch_ref_shift(B, ld, nx, N, d_ref, (hipStream_t)stream));
+    return TG_OK;
+}
+
 int tg_mpc6_reset_warm(tg_mpc6 *h) { if (!h) return fail(TG_E_ARG, "null handle"); h->st.warm_valid = false; return TG_OK; }
 int tg_mpc6_dims(const tg_mpc6 *h, int *n, int *m)
 {
@@ -676,6 +699,29 @@ int tg_mpc12_assemble_host(tg_mpc12 *h, int stage, int B, const double *x0, cons
         HIP_TRY(hipMemcpy(tmp.data(), o.dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
         from_soa(tmp, B, o.rows, ld, o.host);
     }
+    return TG_OK;
+}
+
+int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, const double *d_U, void *stream)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
+    if (B == 0) return TG_OK;
+    if (!d_x0 || !d_U) return fail(TG_E_ARG, "null device array");
+    HIP_TRY(hipSetDevice(h->device));
+    // getTransitionMatrix / getInputMatrix (mpc_12state.cpp:2001-2025): blkdiag(XY, Z, Yaw)
+    double A[144] = {0}, Bm[48] = {0};
+    const int fam[3] = {TG_FAM_XY, TG_FAM_Z, TG_FAM_YAW};
+    int r0 = 0, u0 = 0;
+    for (int f : fam) {
+        const StageModel &m = h->st[f].sp.mdl;
+        for (int i = 0; i < m.nx; i++) {
+            for (int j = 0; j < m.nx; j++) A[(r0 + i) * 12 + r0 + j] = m.Ad[i * m.nx + j];
+            for (int k = 0; k < m.nu; k++) Bm[(r0 + i) * 4 + u0 + k] = m.Bd[i * m.nu + k];
+        }
+        r0 += m.nx; u0 += m.nu;
+    }
+    HIP_TRY(launch_plant_step(12, 4, A, Bm, B, ld, d_x0, d_U, (hipStream_t)stream));
     return TG_OK;
 }
 

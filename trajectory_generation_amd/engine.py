@@ -169,6 +169,18 @@ class BatchedMPC6:
     def reset_warm(self):
         capi.check(self.lib.tg_mpc6_reset_warm(self._h))
 
+    NX, NU = 6, 3
+
+    def plant_step(self, buf, stream=None, B=None):
+        """x0 <- A x0 + B u(0) with the U of the last solve (test_mpc_6dof.cpp:115-122)."""
+        B = buf["B"] if B is None else B
+        capi.check(self.lib.tg_mpc6_plant_step(self._h, B, buf["ld"], _ptr(buf["x0"]), _ptr(buf["U"]),
+                                               _stream_ptr(stream)))
+
+    def ref_shift(self, buf, stream=None, B=None):
+        B = buf["B"] if B is None else B
+        capi.check(self.lib.tg_ref_shift(B, buf["ld"], 6, self.N, _ptr(buf["ref"]), _stream_ptr(stream)))
+
 
 class BatchedMPC12:
     """B independent MPC12STATE::mpcLoop calls per launch (src/mpc_12state.cpp:1374-1453)."""
@@ -289,6 +301,19 @@ class BatchedMPC12:
 
     def reset_warm(self):
         capi.check(self.lib.tg_mpc12_reset_warm(self._h))
+
+    NX, NU = 12, 4
+
+    def plant_step(self, buf, stream=None, B=None):
+        """x0 <- A x0 + B u(0), A / B = getTransitionMatrix / getInputMatrix
+        (test_mpc_12state.cpp:193-197, mpc_12state.cpp:2001-2025)."""
+        B = buf["B"] if B is None else B
+        capi.check(self.lib.tg_mpc12_plant_step(self._h, B, buf["ld"], _ptr(buf["x0"]), _ptr(buf["U"]),
+                                                _stream_ptr(stream)))
+
+    def ref_shift(self, buf, stream=None, B=None):
+        B = buf["B"] if B is None else B
+        capi.check(self.lib.tg_ref_shift(B, buf["ld"], 12, self.params.N, _ptr(buf["ref"]), _stream_ptr(stream)))
 
 
 def timing_enable(on=True):
