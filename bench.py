@@ -42,7 +42,7 @@ def flops_per_iteration(model, N):
     return 2 * ((8 * N + 6) ** 2 + 2 * (4 * N + 3) ** 2)
 
 
-def cpu_baseline(model, N, seed_off, eps, rho, rho_rows):
+def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=5):
     """Reference CPU path restated (OSQP algorithm with its default settings, one instance at a
     time on one core, as the reference runs it) on a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -51,7 +51,8 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows):
     if N >= 50:
         sample //= 8
     out = {}
-    fixed = lambda r: O.fixed_rho_settings(r, warm_start=0, eps_abs=eps, eps_rel=eps)
+    fixed = lambda r: O.fixed_rho_settings(r, warm_start=0, eps_abs=eps, eps_rel=eps, check_termination=check,
+                                           check_fine=check_fine)
     for kind, mk in (("osqp_defaults", lambda: O.default_settings(warm_start=0, eps_abs=eps, eps_rel=eps)),
                      ("engine_algorithm", None)):
         if mk:
@@ -86,6 +87,8 @@ def main():
     ap.add_argument("--workload", default="mpc_6dof_B4096_N20", choices=sorted(WORKLOADS))
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--max-iter", type=int, default=4000, help="ADMM iteration budget per solve (OSQP default 4000)")
+    ap.add_argument("--check", type=int, default=25, help="termination check interval (OSQP default 25)")
+    ap.add_argument("--check-fine", type=int, default=None, help="check interval after the first check (0: OSQP's fixed interval)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -102,7 +105,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     model, B, N, seed_off = WORKLOADS[args.workload]
-    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter)
+    if args.check_fine is None:
+        # 6-DOF open-loop batches: after the first check test every 5 iterations, so a tile of 16
+        # instances does not wait for the next multiple of 25.  Closed loop and the 12-state chain
+        # keep OSQP's interval: their iterates feed a next problem (next step's initial state, the
+        # XY bounds, the yaw reference), and iterates nearer the tolerance make more of those
+        # infeasible or slow to certify as such.
+        args.check_fine = 5 if args.workload.startswith("mpc_6dof") else 0
+    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check, check_fine=args.check_fine)
     first = rank * B                       # weak scaling: every rank owns its own slab of B instances
     if model == "6dof":
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts, device=local)
@@ -203,7 +213,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "model": None, "instances_per_gpu": B, "horizon_N": N,
-                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "rho": eng.rho if model == "6dof" else
+                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "rho": eng.rho if model == "6dof" else
                    [eng.rho(k) for k in ("xy", "z", "yaw")], "parallelism": "instances sharded x%d" % world},
         "p50_batch_ms": float(np.median(lat)),
         "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),
@@ -217,7 +227,7 @@ def main():
     }
     del out["config"]["model"]
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(model, N, seed_off, args.eps, out["config"]["rho"], eng.rho_rows())
+        out["cpu_baseline"] = cpu_baseline(model, N, seed_off, args.eps, out["config"]["rho"], eng.rho_rows(), args.check, args.check_fine)
         if closed:
             out["cpu_baseline"]["sample"] += "; cold-started single solves of the same problems (the closed-loop GPU " \
                                              "steps are warm-started)"

@@ -81,6 +81,14 @@ typedef struct {
      * every termination check; 0 switches the test off.  Dual infeasibility cannot occur: the
      * inputs are boxed and the dynamics rows tie every state to them. */
     double eps_prim_inf;
+    /* > 0: after the first termination check (at iteration check_termination) test every
+     * check_fine iterations instead of every check_termination.  In a batch a tile of 16
+     * instances runs until its slowest member passes the test, and most instances pass it a few
+     * iterations after the first check; OSQP's fixed interval would make them all wait for the
+     * next multiple of 25.  Every returned iterate passes the same eps_abs / eps_rel test.
+     * Earlier stops mean iterates that sit closer to the tolerance.  Default 0 = OSQP's fixed
+     * interval. */
+    int    check_fine;
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

@@ -46,6 +46,10 @@ typedef struct {
     int    warm_start;             /* reference: 1 for MPC (mpc_6dof.cpp:528), 0 for
                                       MPC12STATE (mpc_12state.cpp:1025,1045,1065) */
     int    scaled_termination;     /* 0     */
+    int    check_fine;             /* NOT an OSQP setting: > 0 = after the first check (at
+                                      check_termination) test every check_fine iterations, so the
+                                      checker can follow the engine's check schedule; 0 = OSQP's
+                                      fixed interval */
 } osqp_settings;
 
 enum {

@@ -133,12 +133,14 @@ void osqp_default_settings(osqp_settings *s)
     s->max_iter = 4000; s->check_termination = 25;
     s->scaling = 10; s->adaptive_rho = 1; s->adaptive_rho_interval = 0;
     s->adaptive_rho_tolerance = 5.0; s->warm_start = 1; s->scaled_termination = 0;
+    s->check_fine = 0;
 }
 
 void osqp_fixed_rho_settings(osqp_settings *s, double rho)
 {
     osqp_default_settings(s);
     s->rho = rho; s->scaling = 0; s->adaptive_rho = 0;
+    s->check_fine = 0;
 }
 
 /* ---------------------------------------------------------------- scaling (sec. 5.1) */
@@ -520,6 +522,9 @@ int osqp_solve(osqp_work *w)
             w->y[i] += w->delta_y[i];
         }
         checked = w->s.check_termination && (iter % w->s.check_termination == 0);
+        if (w->s.check_termination && w->s.check_fine > 0)
+            checked = iter >= w->s.check_termination &&
+                      (iter - w->s.check_termination) % w->s.check_fine == 0;
         if (checked) {
             update_info(w);
             if (check_termination(w, 0)) break;

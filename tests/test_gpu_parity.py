@@ -70,7 +70,7 @@ def test_matrices_bit_exact_6dof(tg, oracle, N, smooth):
     cls = oracle.match_rho_classes(eng.rho_rows())
     same = rho == eng1.get(capi.TG_VEC_RHO)
     Nx = 6 * (N + 1)
-    assert same[:Nx].all() and cls == (20.0, 3.0, 1.0, 5.0)
+    assert same[:Nx].all() and cls == ((15.0, 1.0, 1.0, 3.0) if N <= 30 else (20.0, 3.0, 1.0, 5.0))
 
 
 @pytest.mark.parametrize("N,B", [(5, 1), (20, 37), (50, 16)])
@@ -139,21 +139,24 @@ def test_assembly_and_matrices_bit_exact_12state(tg, oracle):
     (5, 1, 1e-3, False, None), (10, 16, 1e-3, True, None), (20, 64, 1e-3, False, None),
     (20, 37, 1e-5, False, None), (20, 48, 1e-3, True, None), (50, 32, 1e-3, False, None),
     (20, 64, 1e-3, False, (1, 1, 1, 1)), (50, 16, 1e-3, False, (1, 1, 1, 1)), (20, 33, 1e-4, True, (7, 2, 1, 0.5))])
-def test_solve_matches_oracle_6dof(tg, oracle, N, B, eps, smooth, scale):
+@pytest.mark.parametrize("fine", [0, 5])
+def test_solve_matches_oracle_6dof(tg, oracle, N, B, eps, smooth, scale, fine):
     kw = dict(N=N, enable_control_smoothing=smooth)
     p, op = _p6_pair(tg, oracle, **kw)
-    eng = tg.BatchedMPC6(p, tg.make_opts(eps_abs=eps, eps_rel=eps, rho_scale=scale or (0, 0, 0, 0)))
+    eng = tg.BatchedMPC6(p, tg.make_opts(eps_abs=eps, eps_rel=eps, rho_scale=scale or (0, 0, 0, 0), check_fine=fine))
     x0, ref = oracle.synth_mpc6(SEED + 2, N, 0.1, B)
     r = eng.solve_host(x0, ref)
     oracle.match_rho_classes(eng.rho_rows())
-    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, eps_abs=eps, eps_rel=eps, warm_start=0), x0, ref)
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, eps_abs=eps, eps_rel=eps, warm_start=0,
+                                                         check_fine=fine), x0, ref)
     assert (r["status"] == 1).all() and (ro["status"] == 1).all()
+    assert fine == 0 or ((r["iters"] - 25) % 5 == 0).all()
     np.testing.assert_array_equal(r["iters"], ro["iters"])
     assert np.abs(r["X"] - ro["X"]).max() < 1e-9 and np.abs(r["U"] - ro["U"]).max() < 1e-9
 
 
-def test_solve_matches_oracle_12state(tg, oracle):
-    N, B = 20, 32
+@pytest.mark.parametrize("N,B", [(20, 32), (5, 3), (50, 5), (1, 2)])
+def test_solve_matches_oracle_12state(tg, oracle, N, B):
     eng = tg.BatchedMPC12(tg.mpc12_params(N=N))
     op = oracle.mpc12_params(N=N)
     x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B)
@@ -161,8 +164,11 @@ def test_solve_matches_oracle_12state(tg, oracle):
     s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
     oracle.match_rho_classes(eng.rho_rows())
     ro = oracle.mpc12_batch(op, s, x12, ref12)
-    assert (r["status"] == 1).all() and (ro["status"] == 1).all()
+    np.testing.assert_array_equal(r["status"], ro["status"])
     np.testing.assert_array_equal(r["iters"], ro["iters"])
+    ok = (r["status"] == 1).all(1)
+    assert ok.mean() >= 0.5
+    r = {k: v[ok] for k, v in r.items()}; ro = {k: v[ok] for k, v in ro.items() if k != "n_ok"}
     # the yaw reference goes through atan2 (<= 4 ulp apart), everything else is the same arithmetic
     assert np.abs(r["X"] - ro["X"]).max() < 1e-8 and np.abs(r["U"] - ro["U"]).max() < 1e-8
 
@@ -485,3 +491,21 @@ def test_closed_loop_rollout_matches_oracle(tg, oracle, model):
     assert worst < 1e-7, worst
     # the reference array on the device moved the same way
     assert np.abs(buf["ref"][:, :B].cpu().numpy().T[B - 1] - r).max() < 1e-9
+
+
+def test_horizon_limits_are_reported(tg, oracle):
+    """Horizons beyond what the on-chip iterates allow are refused with a message, not mis-solved."""
+    from trajectory_generation_amd import _capi as capi
+    N = 1
+    p, op = _p6_pair(tg, oracle, N=N)
+    eng = tg.BatchedMPC6(p)
+    x0, ref = oracle.synth_mpc6(5, N, 0.1, 3)
+    r = eng.solve_host(x0, ref)
+    oracle.match_rho_classes(eng.rho_rows())
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
+    np.testing.assert_array_equal(r["iters"], ro["iters"])
+    assert np.abs(r["X"] - ro["X"]).max() < 1e-9
+    with pytest.raises(capi.TgError) as e:
+        big = tg.BatchedMPC6(tg.mpc6_params(N=120))
+        big.solve_host(np.zeros((1, 6)), np.zeros((1, 6 * 121)))
+    assert "horizon" in str(e.value)

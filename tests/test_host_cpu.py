@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     o = capi.SolverOpts()
     lib.tg_default_opts(C.byref(o))
     got = (o.sigma, o.alpha, o.eps_abs, o.eps_rel, o.max_iter, o.check_termination)
-    assert got == (1e-6, 1.6, 1e-3, 1e-3, 4000, 25)
+    assert got == (1e-6, 1.6, 1e-3, 1e-3, 4000, 25) and o.check_fine == 0 and o.eps_prim_inf == 1e-4
 
 
 def test_argument_errors_do_not_need_a_gpu():

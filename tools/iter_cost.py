@@ -7,7 +7,7 @@ import trajectory_generation_amd as tg
 from trajectory_generation_amd import synth
 
 def run(model, N, B, iters=200, reps=5, check=25):
-    opts = tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=check, eps_prim_inf=0.0)
+    opts = tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=check, eps_prim_inf=0.0, check_fine=0)
     if model == "6dof":
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts); x0, ref = synth.mpc6(1, N, 0.1, B)
         flops = 3 * 2 * (3 * N + 2) ** 2

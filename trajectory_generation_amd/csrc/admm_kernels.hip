@@ -470,8 +470,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
     };
 
     for (int iter = 0; iter < max_iter;) {
-        // iterations up to the next check: every `check` iterations and at max_iter
-        const int burst = min(check, max_iter - iter);
+        // iterations up to the next check: at `check`, then every `check_fine` (or every `check`
+        // when check_fine is 0), and at max_iter
+        const int gap = (P.check_fine > 0 && iter >= check) ? P.check_fine : check;
+        const int burst = min(gap, max_iter - iter);
         for (int i = 1; i < burst; i++) {
             step(std::false_type{});
             __syncthreads();

@@ -46,7 +46,7 @@ struct StageDev {
     int x0_slot;                 // same for x0
     int U_stride, U_off[kMaxAxes];
     double sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
-    int max_iter, check;
+    int max_iter, check, check_fine;
 };
 
 // reference-ordered tables for the assembly kernel

@@ -147,7 +147,7 @@ struct DevStage {
             dev.separate_xt = rows2 * 16 * 8 + 1024 <= 80 * 1024 ? 1 : 0;
         }
         dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
-        dev.max_iter = o.max_iter; dev.check = o.check_termination;
+        dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
         adev.n = sp.n; adev.m = sp.m; adev.rows_per_block = 32;
         adev.q_w = d_qw; adev.l_t = d_lt; adev.u_t = d_ut; adev.q_ref_row = d_qrr;
         adev.x0_row = d_x0r; adev.ov_box = d_ovb; adev.ov_mixed = d_ovm;
@@ -252,7 +252,7 @@ static void from_soa(const std::vector<double> &soa, int B, int rows, int ld, do
 static int check_opts(const tg_solver_opts &o)
 {
     if (!(o.sigma > 0) || !(o.alpha > 0 && o.alpha < 2) || !(o.eps_abs >= 0) || !(o.eps_rel >= 0) || !(o.eps_prim_inf >= 0) ||
-        o.max_iter < 1 || o.check_termination < 1)
+        o.max_iter < 1 || o.check_termination < 1 || o.check_fine < 0)
         return fail(TG_E_ARG, "invalid solver options");
     for (int k = 0; k < 4; k++)
         if (!(o.rho_scale[k] >= 0)) return fail(TG_E_ARG, "rho_scale entries must be >= 0");
@@ -264,7 +264,7 @@ extern "C" {
 void tg_default_opts(tg_solver_opts *o)
 {
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
-    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4;
+    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0;
     for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }

@@ -125,11 +125,16 @@ inline bool spd_inverse(const std::vector<double> &K, int n, std::vector<double>
 // A uniform rho leaves a long iteration tail on instances whose position or input rows are
 // active (the 6-DOF altitude floor, saturated inputs): the step those rows need is set by the
 // state / input weights, not by their geometric mean.  Values picked from sweeps over 4096
-// random instances at N = 20 and N = 50 (tools/gpu_rho_sweep.py): they bring the slowest 6-DOF
-// instance from 375 (N = 20) / 825 (N = 50) iterations to 50 / 75 at eps 1e-3.
+// random instances at N = 20 and N = 50 (tools/gpu_rho_sweep.py, tools/iter_need.py): they bring
+// the slowest 6-DOF instance from 375 (N = 20) / 825 (N = 50) iterations to 30 / 60 at eps 1e-3,
+// with 99.9 % (N = 20) of the instances done by iteration 25.  Longer horizons want a larger step
+// on the altitude floor rows (a violation builds up over more steps).
 inline void default_rho_scale(const StageModel &mdl, double out[4])
 {
-    if (mdl.family == TG_FAM_6DOF) { out[0] = 20.0; out[1] = 3.0; out[2] = 1.0; out[3] = 5.0; }
+    if (mdl.family == TG_FAM_6DOF) {
+        if (mdl.N <= 30) { out[0] = 15.0; out[1] = 1.0; out[2] = 1.0; out[3] = 3.0; }
+        else { out[0] = 20.0; out[1] = 3.0; out[2] = 1.0; out[3] = 5.0; }
+    }
     else { out[0] = 1.0; out[1] = 3.0; out[2] = 1.0; out[3] = 3.0; }
 }
 
