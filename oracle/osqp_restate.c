@@ -453,16 +453,19 @@ static int is_dual_infeasible(osqp_work *w, double eps)
     return 0;
 }
 
-static int check_termination(osqp_work *w, int approximate)
+static int check_termination_ex(osqp_work *w, int approximate, int test_infeasibility);
+static int check_termination(osqp_work *w, int approximate) { return check_termination_ex(w, approximate, 1); }
+
+static int check_termination_ex(osqp_work *w, int approximate, int test_infeasibility)
 {
     double ea = w->s.eps_abs, er = w->s.eps_rel, epi = w->s.eps_prim_inf, edi = w->s.eps_dual_inf;
     if (approximate) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
     int prim_ok = 0, dual_ok = 0, prim_inf = 0, dual_inf = 0;
     if (w->m == 0) prim_ok = 1;
     else if (w->pri_res < eps_prim(w, ea, er)) prim_ok = 1;
-    else prim_inf = is_primal_infeasible(w, epi);
+    else if (test_infeasibility) prim_inf = is_primal_infeasible(w, epi);
     if (w->dua_res < eps_dual(w, ea, er)) dual_ok = 1;
-    else dual_inf = is_dual_infeasible(w, edi);
+    else if (test_infeasibility) dual_inf = is_dual_infeasible(w, edi);
     if (prim_ok && dual_ok) { w->status = approximate ? 2 : ORACLE_SOLVED; return 1; }
     if (prim_inf) { w->status = approximate ? 3 : ORACLE_PRIMAL_INFEASIBLE; return 1; }
     if (dual_inf) { w->status = approximate ? 4 : ORACLE_DUAL_INFEASIBLE; return 1; }
@@ -527,7 +530,10 @@ int osqp_solve(osqp_work *w)
                       (iter - w->s.check_termination) % w->s.check_fine == 0;
         if (checked) {
             update_info(w);
-            if (check_termination(w, 0)) break;
+            /* with the finer schedule the infeasibility certificates are tested only where OSQP's
+               own schedule has a check */
+            int full = w->s.check_fine <= 0 || iter % w->s.check_termination == 0 || iter == w->s.max_iter;
+            if (check_termination_ex(w, 0, full)) break;
         }
         if (w->s.adaptive_rho && w->s.adaptive_rho_interval &&
             (iter % w->s.adaptive_rho_interval == 0)) {

@@ -346,18 +346,18 @@ def test_ragged_empty_and_padding(tg, oracle):
         eng.solve(buf, B=ld + 1)                    # B > ld is rejected
 
 
-def test_infeasible_instance_reports_failure(tg, oracle):
+@pytest.mark.parametrize("fine", [0, 5])
+def test_infeasible_instance_reports_failure(tg, oracle, fine):
     """OSQP's primal infeasibility certificate, tested at every termination check: same status
     and detection iteration as the oracle; without the test the instance runs to max_iter."""
     N = 10
     p, op = _p6_pair(tg, oracle, N=N)
     x0, ref = oracle.synth_mpc6(3, N, 0.1, 4)
     x0[2, 3] = 50.0                                 # |v_x(0)| > v_max: step-0 box contradicts x(0) = x0
-    eng = tg.BatchedMPC6(p)
-    sentinel = np.full((4, 6 * (N + 1)), -7.0)
+    eng = tg.BatchedMPC6(p, tg.make_opts(check_fine=fine))
     r = eng.solve_host(x0, ref)
     oracle.match_rho_classes(eng.rho_rows())
-    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0, check_fine=fine), x0, ref)
     assert r["status"][2] == -3 and ro["status"][2] == oracle.PRIMAL_INFEASIBLE
     np.testing.assert_array_equal(r["iters"], ro["iters"])
     assert (np.delete(r["status"], 2) == 1).all()   # the neighbours in the same tile are unaffected

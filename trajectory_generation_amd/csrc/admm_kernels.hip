@@ -479,14 +479,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
             __syncthreads();
         }
         iter += burst;
-        step(std::true_type{});
+        // the infeasibility certificate is tested where OSQP's own schedule has a check (multiples
+        // of `check`, and the last iteration); the finer checks in between only test convergence
+        const bool full = P.check_fine <= 0 || iter % check == 0 || iter == max_iter;
+        if (full) step(std::true_type{}); else step(std::false_type{});
         // -------------------------------------------------------- termination check
         {
             __syncthreads();
             // ||A' delta_y||_inf: own part + the next step's dynamics rows + the mixed rows
             double m_atdy = 0.0;
 #pragma unroll
-            for (int cc = 0; cc < MAXC; cc++) {
+            for (int cc = 0; cc < (full ? MAXC : 0); cc++) {
                 double dn[D], mixc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                 for (int k = 0; k < D; k++) dn[k] = lds[i_wnext[cc] + k * 16];
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
                 }
                 m_atdy = fmax(m_atdy, fabs(part[cc][D] + dt * dn[D - 1]));
             }
-            __syncthreads();
+            if (full) __syncthreads();
             if (g == 0) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) if (k != 6) red[k * 16 + t] = 0ull;
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
             // OSQP's certificate of primal infeasibility (is_primal_infeasible, only tried while
             // the primal residual is above its tolerance): delta_y, projected on the polar of the
             // recession cone of [l, u], separates the constraint set from the range of A
-            const bool pinf = !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
+            const bool pinf = full && !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
                               pin_l < -eps_pinf * pin_n && m_atdy < eps_pinf * pin_n;
             if (!done && (conv || pinf || iter == max_iter)) {
                 done = true;
