@@ -82,13 +82,15 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=5)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="mpc_6dof_B4096_N20", choices=sorted(WORKLOADS))
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--max-iter", type=int, default=4000, help="ADMM iteration budget per solve (OSQP default 4000)")
     ap.add_argument("--check", type=int, default=25, help="termination check interval (OSQP default 25)")
     ap.add_argument("--check-fine", type=int, default=None, help="check interval after the first check (0: OSQP's fixed interval)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -100,9 +102,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
+    red_dev = "cuda" if args.backend == "nccl" else "cpu"    # where the few statistics are reduced
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     model, B, N, seed_off = WORKLOADS[args.workload]
     if args.check_fine is None:
@@ -147,7 +154,7 @@ def main():
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -179,8 +186,8 @@ def main():
     iters = buf["iters"].cpu().numpy().reshape(-1, buf["ld"])[:, :B]
     status = buf["status"].cpu().numpy().reshape(-1, buf["ld"])[:, :B]
     stats = torch.tensor([float(iters.sum()), float((status == 1).all(0).sum()), float(B)],
-                         dtype=torch.float64, device="cuda")
-    imax = torch.tensor([float(iters.max())], dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device=red_dev)
+    imax = torch.tensor([float(iters.max())], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(imax, op=dist.ReduceOp.MAX)
