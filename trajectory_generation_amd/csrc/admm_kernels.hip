@@ -24,7 +24,7 @@
 #include "device_types.h"
 
 #ifndef TG_ABLATE
-#define TG_ABLATE 0   // development: 1 = no MFMA, 2 = no rhs phase, 3 = no projection phase
+#define TG_ABLATE 0   // development, bit mask: 1 = no MFMA, 2 = no rhs phase, 4 = no projection phase
 #endif
 
 namespace tg {
@@ -72,7 +72,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
 //   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
-__global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const StageDev P, const BatchArgs a)
+__global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
     constexpr int kThreads = NT, kWaves = NT / 64, kStride = NT / kTileDev;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
     const int BGT = ZERO + 8 * 16;                                           // [NAX][D][16] -x0: l = u of the step-0 rows
     const int CTAB = BGT + NAX * D * 16;                                     // [NAX][S][3] rho, lb, ub
     unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
-    double *rsum = (double *)(red + 9 * 16);                                        // [8 waves][16] partial sums
+    double *rsum = (double *)(red + 9 * 16);                                        // [waves][16] partial sums
     double *v0 = lds + V0, *vx = lds + VX;
 
     const double sigma = P.sigma, alpha = P.alpha, oma = 1.0 - P.alpha;
@@ -232,8 +232,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
 
     const int nit = P.wi_cnt[wave];
     double mreg[KSREG > 0 ? KSREG : 1];
+    // the single MFMA item of a wave whose fragments are register resident, looked up once
+    const int grp_r = P.wi_grp[wave][0], rb_r = P.wi_rb[wave][0];
+    const bool two_r = PAIR && P.grp_cnt[grp_r] == 2;
+    const int boff_r = (P.grp_first[grp_r] * nb + (lane >> 4)) * 16 + (lane & 15);
     if constexpr (KSREG > 0) {
-        const int grp = P.wi_grp[wave][0], rb = P.wi_rb[wave][0];
+        const int grp = grp_r, rb = rb_r;
 #pragma unroll
         for (int kk = 0; kk < KSREG; kk++) {
             const bool in = nit > 0 && kk < ks;
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
         constexpr bool CHK = decltype(chk_c)::value;
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
 #pragma unroll
-        for (int cc = 0; cc < (TG_ABLATE == 2 ? 0 : MAXC); cc++) {
+        for (int cc = 0; cc < ((TG_ABLATE & 2) ? 0 : MAXC); cc++) {
             const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
             double wn[D], wo[D];
 #pragma unroll
@@ -302,26 +306,37 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
                 acc0[it] = (d4){0, 0, 0, 0};
                 if (PAIR) acc1[it] = (d4){0, 0, 0, 0};
                 if (it < nit) {
-                    const int grp = P.wi_grp[wave][it], rb = P.wi_rb[wave][it];
-                    const bool two = PAIR && P.grp_cnt[grp] == 2;
-                    const double *bp0 = v0 + ((size_t)P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15);
+                    const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
+                    const bool two = KSREG > 0 ? two_r : (PAIR && P.grp_cnt[grp] == 2);
+                    const double *bp0 = v0 + (KSREG > 0 ? boff_r : (P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15));
                     const double *bp1 = bp0 + (size_t)nb * 16;
                     if constexpr (KSREG > 0) {
+                        // ks == KSREG here (host dispatch): all B operands are fetched before the
+                        // first MFMA and the chain has no branches
+                        auto run = [&](auto two_c) __attribute__((always_inline)) {
+                            constexpr bool TWO = decltype(two_c)::value;
+                            double bf0[KSREG], bf1[TWO ? KSREG : 1];
 #pragma unroll
-                        for (int kk = 0; kk < KSREG; kk++) {
-                            if (kk < ks) {
-                                const double bf0 = bp0[kk * 64];
-#if TG_ABLATE != 1
-                                acc0[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0, acc0[0], 0, 0, 0);
-                                if (PAIR && two) {
-                                    const double bf1 = bp1[kk * 64];
-                                    acc1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf1, acc1[0], 0, 0, 0);
-                                }
+                            for (int kk = 0; kk < KSREG; kk++) {
+                                bf0[kk] = bp0[kk * 64];
+                                if constexpr (TWO) bf1[kk] = bp1[kk * 64];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA chain
+                            d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+#pragma unroll
+                            for (int kk = 0; kk < KSREG; kk++) {
+#if !(TG_ABLATE & 1)
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c0, 0, 0, 0);
+                                if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf1[kk], c1, 0, 0, 0);
 #else
-                                acc0[0][0] += mreg[kk] * bf0;
+                                c0[0] += mreg[kk] * bf0[kk];
+                                if constexpr (TWO) c1[0] += mreg[kk] * bf1[kk];
 #endif
                             }
-                        }
+                            acc0[0] = c0;
+                            if constexpr (PAIR) acc1[0] = c1;
+                        };
+                        if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
                     } else {
                         // ring of kRingDepth fragments in flight; the fragment array carries
                         // kRingDepth zero steps of padding, so the prefetch needs no bounds test and
@@ -373,11 +388,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
                 if (it < nit) {
-                    const int grp = P.wi_grp[wave][it], rb = P.wi_rb[wave][it];
-                    double *o0 = vx + ((size_t)P.grp_first[grp] * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
+                    const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
+                    double *o0 = vx + (KSREG > 0 ? boff_r + rb * 256 : (P.grp_first[grp] * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15));
 #pragma unroll
                     for (int r = 0; r < 4; r++) o0[r * 64] = acc0[it][r];
-                    if (PAIR && P.grp_cnt[grp] == 2) {
+                    if (PAIR && (KSREG > 0 ? two_r : P.grp_cnt[grp] == 2)) {
                         double *o1 = o0 + (size_t)nb * 16;
 #pragma unroll
                         for (int r = 0; r < 4; r++) o1[r * 64] = acc1[it][r];
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 2 : 1) void admm_kernel(const Stage
         if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; }
         {
 #pragma unroll
-            for (int cc = 0; cc < (TG_ABLATE == 3 ? 0 : MAXC); cc++) {
+            for (int cc = 0; cc < ((TG_ABLATE & 4) ? 0 : MAXC); cc++) {
                 const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
                 const double *xin = vx + i_var[cc];
                 const double *xpr = lds + i_prev[cc];
@@ -851,7 +866,7 @@ size_t admm_lds_bytes(const StageDev &P)
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
                   (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D;
-    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + 8) * 16 * sizeof(double);
+    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves) * 16 * sizeof(double);
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
@@ -875,15 +890,20 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     int needi = 0;
     for (int w = 0; w < P.nwaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
     if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
-    if (P.nwaves != 8) { *why = "only 8-wave workgroups are compiled"; return hipErrorInvalidValue; }
+    if (P.nwaves == 16) {
+        if (P.D == 2 && P.nax == 3 && !P.mixed && needc <= 1 && needi <= 1 && P.ks == 16)
+            return launch_admm_t<1024, 2, 3, false, 1, 1, true, 16>(P, a, s);
+        *why = "no 16-wave kernel variant for this stage";
+        return hipErrorInvalidValue;
+    }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (needc <= 2 && needi <= 1 && P.ks <= 16) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16>(P, a, s);
+        if (needc <= 2 && needi <= 1 && P.ks == 16) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16>(P, a, s);
         if (needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
         if (needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0>(P, a, s);
         if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0>(P, a, s);
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (needc <= 1 && needi <= 1 && P.ks <= 24) return launch_admm_t<512, 3, 1, false, 1, 1, false, 24>(P, a, s);
+        if (needc <= 1 && needi <= 1 && P.ks == 24) return launch_admm_t<512, 3, 1, false, 1, 1, false, 24>(P, a, s);
         if (needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0>(P, a, s);
     }
     *why = "horizon too long for the compiled kernel variants";

@@ -10,7 +10,7 @@ constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2, TG_DEV_PRIMAL_INFEASIBLE 
 constexpr double kInfBound = 1e26;      // OSQP_INFTY * MIN_SCALING: bounds beyond it count as infinite
 constexpr double kDivisionTol = 1e-30;  // 1 / OSQP_INFTY
 constexpr int kMaxAxes = 3, kMaxSlots = 4;
-constexpr int kAdmmWaves = 8;           // most waves an ADMM workgroup has (StageDev::nwaves: 4 or 8)
+constexpr int kAdmmWaves = 16;          // most waves an ADMM workgroup has (StageDev::nwaves: 8 or 16)
 constexpr int kMaxItems = 8;                                        // MFMA work items per wave
 constexpr int kRingDepth = 8;   // operator fragments (k steps) a wave keeps in flight from L2
 

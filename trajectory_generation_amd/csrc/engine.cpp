@@ -92,6 +92,7 @@ struct DevStage {
         dev.N = mdl.N; dev.D = sp.D; dev.nax = sp.nax; dev.mixed = mdl.n_mixed ? 1 : 0;
         dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = sp.nb / 16; dev.ks = sp.nb / 4; dev.ks_alloc = dev.ks + kRingDepth;
         dev.nwaves = 8;
+        if (const char *e = getenv("TG_ADMM_WAVES")) dev.nwaves = atoi(e) == 16 ? 16 : 8;   // development switch
         // groups of up to two adjacent blocks that share an operator
         dev.ngrp = 0;
         for (int b = 0; b < sp.nblk;) {
@@ -100,7 +101,7 @@ struct DevStage {
             dev.ngrp++; b += cnt;
         }
         // deal the (group, row block) MFMA items: longest first onto the least loaded SIMD
-        // (waves w and w + 4 of a workgroup share a SIMD), then onto its less loaded wave
+        // (waves w, w + 4, ... of a workgroup share a SIMD), then onto its least loaded wave
         {
             struct Item { int grp, rb, cost; };
             std::vector<Item> items;
@@ -112,7 +113,8 @@ struct DevStage {
             for (const Item &it : items) {
                 int sd = 0;
                 for (int k = 1; k < 4; k++) if (simd_load[k] < simd_load[sd]) sd = k;
-                int w = (dev.nwaves == 4 || wave_load[sd] <= wave_load[sd + 4]) ? sd : sd + 4;
+                int w = sd;
+                for (int c = sd + 4; c < dev.nwaves; c += 4) if (wave_load[c] < wave_load[w]) w = c;
                 if (dev.wi_cnt[w] >= kMaxItems) return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
                 dev.wi_grp[w][dev.wi_cnt[w]] = (unsigned char)it.grp;
                 dev.wi_rb[w][dev.wi_cnt[w]] = (unsigned char)it.rb;
