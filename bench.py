@@ -30,7 +30,8 @@ WORKLOADS = {
     "rollout_12state_B8192_N20": ("12state", 8192, 20, 5),
     "rollout_6dof_B8192_N20": ("6dof", 8192, 20, 5),
 }
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD at 2.4 GHz)
+FP64_MFMA_SUSTAINED_TFLOPS = 47.5   # what tools/microbench/mfma_f64_peak.hip sustains on the box (register-only MFMA chains)
 
 
 def flops_per_iteration(model, N):
@@ -148,11 +149,16 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize(); barrier()
+    # HIP events on the launch stream (the engine launches on the null stream, torch's current one)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
+    region_ms = ev0.elapsed_time(ev1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,7 +211,11 @@ def main():
     if model != "6dof":   # per-stage sizes differ: weight the stage iteration counts
         n_stage = {0: 4 * N + 3, 1: 8 * N + 6, 2: 4 * N + 3}
         flops_launch = sum(float(iters[k].sum()) * 2 * n_stage[k] ** 2 for k in range(3)) / 3
-    avg_kernel_ms = kern_ms / max(kern_launches, 1)
+    # average admm_kernel launch over the timed region: event time / launches (the other kernels of a
+    # step -- xy bounds, yaw reference, plant, shift -- are < 1 % of it); the per-launch event pairs
+    # taken after the timed region are reported beside it
+    avg_kernel_ms = region_ms / (args.steps * launches_per_step)
+    per_launch_event_ms = kern_ms / max(kern_launches, 1)
     achieved = flops_launch / (avg_kernel_ms * 1e-3) / 1e12 if avg_kernel_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -229,7 +239,9 @@ def main():
         "pcie_inclusive_solves_per_s_rank0": pcie_rate,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "admm_kernel",
-                     "avg_kernel_ms": avg_kernel_ms, "launches_timed": kern_launches,
+                     "avg_kernel_ms": avg_kernel_ms, "launches_timed": args.steps * launches_per_step,
+                     "per_launch_event_ms": per_launch_event_ms,
+                     "sustained_mfma_microbench": FP64_MFMA_SUSTAINED_TFLOPS,
                      "flops_per_launch": flops_launch},
     }
     del out["config"]["model"]

@@ -20,10 +20,10 @@ def main(src, dst_prefix, workload):
     lines = []
     db = one_db(os.path.join(src, "trace"))
     if db:
-        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 10 --no-cpu-baseline" % workload)
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 200 --no-cpu-baseline" % workload)
         lines.append("%-90s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
-            lines.append("%-90s %8d %14.1f %12.2f %8.3f" % (name[:90], calls, total / 1e3 if total > 1e6 else total, avg / 1e3 if total > 1e6 else avg, pct))
+            lines.append("%-90s %8d %14.1f %12.2f %8.3f" % (name[:90], calls, total, avg, pct))
             if "admm_kernel" in name:
                 out["admm_kernel_avg_us"] = avg
                 out["admm_kernel_calls"] = calls

@@ -874,9 +874,16 @@ static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream
 {
     auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG>;
     const size_t lds_bytes = admm_lds_bytes(P);
-    hipError_t e = hipFuncSetAttribute((const void *)kern,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    // the dynamic LDS limit of a kernel is per device and sticky: raise it when it has to grow
+    static int lds_set[64] = {0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || lds_set[dev] < (int)lds_bytes) {
+        e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 64) lds_set[dev] = (int)lds_bytes;
+    }
     const int grid = (a.B + kTileDev - 1) / kTileDev;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, s, P, a);
     return hipGetLastError();
