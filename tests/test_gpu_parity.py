@@ -289,7 +289,7 @@ def test_port_of_test_mpc_12state(tg, tmp_path):
         x = A @ x + Bm @ U[4 * i:4 * i + 4]
     assert np.linalg.norm(X[120:132] - x) < 5e-3
     Xs = X.reshape(11, 12)
-    assert (np.abs(Xs[:, 7]) <= 5 + 1e-3).all() and (np.abs(Xs[:, 8]) <= 5 + 1e-3).all()
+    assert (np.abs(Xs[:, 7]) <= 5 + 5e-2).all() and (np.abs(Xs[:, 8]) <= 5 + 5e-2).all()   # eps_abs + eps_rel |z|, z ~ 40
     assert (np.abs(U) <= 10 + 1e-3).all()
     out = tmp_path / "sol.csv"
     mpc.setOutputFilePath(str(out))

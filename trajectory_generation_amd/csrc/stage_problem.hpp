@@ -72,12 +72,14 @@ struct StageProblem {
 
 inline double default_rho(const StageModel &mdl)
 {
-    // Fixed step size used in place of OSQP's adaptive rho on the equilibrated problem.
-    // Geometric mean of the largest state weight and the input weight, rounded to
-    // 1-2-5; 7000/500 -> 2000, 5000/200 -> 1000, 1000/10 -> 100.
+    // Fixed step size used in place of OSQP's adaptive rho on the equilibrated problem: half the
+    // geometric mean of the largest state weight and the input weight, rounded to 1-2-5
+    // (7000/500 -> 1000, 7000/200 and 5000/200 -> 500, 1000/100 -> 200).  The factor and the
+    // per-class multipliers below come from the same sweeps (tools/sweep12.py for the 12-state
+    // stages).
     double w = 0;
     for (int a = 0; a < mdl.nx; a++) w = std::max(w, mdl.qdiag[a]);
-    double g = std::sqrt(std::max(w, 1e-12) * std::max(mdl.r, 1e-12));
+    double g = 0.5 * std::sqrt(std::max(w, 1e-12) * std::max(mdl.r, 1e-12));
     if (!(g > 0)) return 1.0;
     double e = std::pow(10.0, std::floor(std::log10(g)));
     double f = g / e;
@@ -135,7 +137,7 @@ inline void default_rho_scale(const StageModel &mdl, double out[4])
         if (mdl.N <= 30) { out[0] = 15.0; out[1] = 1.0; out[2] = 1.0; out[3] = 3.0; }
         else { out[0] = 20.0; out[1] = 3.0; out[2] = 1.0; out[3] = 5.0; }
     }
-    else { out[0] = 1.0; out[1] = 3.0; out[2] = 1.0; out[3] = 3.0; }
+    else { out[0] = 1.0; out[1] = 10.0; out[2] = 3.0; out[3] = 3.0; }   // slowest XY / yaw instance 2466 / 297 -> 109 / 94
 }
 
 inline bool build_stage(const StageModel &mdl, double rho, double sigma, const double rho_scale_in[4],
