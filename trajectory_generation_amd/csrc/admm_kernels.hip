@@ -119,15 +119,21 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     double yg[MAXC][D];
     double q[MAXC];                                // q of the position slot
     double hiv[MIXED ? MAXC : 1][2];               // XY: |v|, |a| box of the cell (per instance)
-    double zm[MIXED ? MAXC : 1][6], ym[MIXED ? MAXC : 1][6], ovm[MIXED ? MAXC : 1][6];
+    // XY mixed rows (mpc_12state.cpp:600-630): the 6 rows of step m = g, g + NT/16, ... belong to
+    // thread group g as a unit of their own, whichever thread owns the two cells of that step.
+    // Their bounds are +-vb on the 4 velocity rows and +-am on the 2 acceleration rows
+    // (computeXYBounds, mpc_12state.cpp:758-779).
+    constexpr int MAXM = MIXED ? (MAXC + 1) / 2 : 1;
+    double zm[MAXM][6], ym[MAXM][6], mvb[MAXM], mam[MAXM];
+    int i_mw[MAXM];      // absolute index of the step's mixed-row w in WMX (spare rows when inactive)
+    int i_mv[MAXM][2];   // index of the step's cell of axis 0 / 1, relative to VX
+    bool mact[MAXM];
     int i_var[MAXC];     // index of the cell's first variable, relative to V0 / VX
     int i_prev[MAXC];    // absolute index of the previous cell's variables in VX (or ZERO)
     int i_wnext[MAXC];   // absolute index of the next cell's dynamics-row w (or ZERO)
     int i_ct[MAXC];      // absolute index of the cell's axis in the constant table
     int i_bg[MAXC];      // absolute index of the cell's dynamics-row bound (BGT at step 0, else ZERO)
     int i_mx[MIXED ? MAXC : 1];     // absolute index of the step's mixed-row w (or ZERO)
-    int i_oth[MIXED ? MAXC : 1];    // XY: index of the other axis' cell of the same step, rel. to VX
-    bool mixrow[MIXED ? MAXC : 1];  // this cell updates the mixed rows of its step
     bool axis0[MIXED ? MAXC : 1];
 
     double qn = 0.0;
@@ -154,15 +160,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
         for (int k = 0; k < D; k++) { zg0[k] = 0.0; yg[cc][k] = 0.0; b0[k] = 0.0; }
         if (MIXED) {
-            const int oth = ax == 0 ? P.axis_base[1] : P.axis_base[0];
-            i_oth[cc] = act ? (oth + st * S) * 16 + t : n_int * 16 + t;
             i_mx[cc] = (act && st >= 1) ? WMX + st * 6 * 16 + t : ZERO + t;
-            mixrow[cc] = act && ax == 0 && st >= 1;
             axis0[cc] = ax == 0;
             hiv[cc][0] = lds[i_ct[cc] + 1 * 3 + 2];
             hiv[cc][1] = lds[i_ct[cc] + 2 * 3 + 2];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { zm[cc][k] = 0.0; ym[cc][k] = 0.0; ovm[cc][k] = 0.0; }
         }
         if (act && valid) {
             q[cc] = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
@@ -178,10 +179,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 const size_t r0 = (size_t)(6 * (st - 1) + 3 * ax) * a.ov_ld + inst;
                 hiv[cc][0] = a.ov_box[r0 + (size_t)a.ov_ld];
                 hiv[cc][1] = a.ov_box[r0 + (size_t)2 * a.ov_ld];
-                if (ax == 0) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) ovm[cc][k] = a.ov_mixed[(size_t)(6 * (st - 1) + k) * a.ov_ld + inst];
-                }
             }
             if (a.warm_in) {
                 const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
@@ -197,14 +194,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     zg0[k] = a.warm[e0 + (size_t)k * a.ldw];
                     yg[cc][k] = a.warm[e0 + (size_t)(ncell * D + k) * a.ldw];
                 }
-                if (MIXED && ax == 0) {
-                    const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + st * 6) * a.ldw + inst;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        zm[cc][k] = a.warm[m0 + (size_t)k * a.ldw];
-                        ym[cc][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw];
-                    }
-                }
             }
         }
         // w of the cell's rows for the first rhs (unused slots write the spare rows at the end)
@@ -216,11 +205,33 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // alpha zt + (1-alpha) z0 + y = alpha zt + (1-alpha) b + [y + (1-alpha)(z0 - b)]
             yg[cc][k] += oma * (zg0[k] - b0[k]);
         }
-        if (MIXED) {
-            if (mixrow[cc]) {
+    }
+    if (MIXED) {
 #pragma unroll
-                for (int k = 0; k < 6; k++) lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
+        for (int mm = 0; mm < MAXM; mm++) {
+            const int m = g + kStride * mm;
+            mact[mm] = m >= 1 && m <= N;
+            const int ms = mact[mm] ? m : 0;
+            i_mw[mm] = mact[mm] ? WMX + m * 6 * 16 + t : WMX + N1 * 6 * 16 + t;
+            i_mv[mm][0] = (P.axis_base[0] + ms * S) * 16 + t;
+            i_mv[mm][1] = (P.axis_base[1] + ms * S) * 16 + t;
+            mvb[mm] = 0.0; mam[mm] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { zm[mm][k] = 0.0; ym[mm][k] = 0.0; }
+            if (mact[mm] && valid) {
+                mvb[mm] = a.ov_mixed[(size_t)(6 * (m - 1) + 0) * a.ov_ld + inst];
+                mam[mm] = a.ov_mixed[(size_t)(6 * (m - 1) + 4) * a.ov_ld + inst];
+                if (a.warm_in) {
+                    const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + m * 6) * a.ldw + inst;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        zm[mm][k] = a.warm[m0 + (size_t)k * a.ldw];
+                        ym[mm][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw];
+                    }
+                }
             }
+#pragma unroll
+            for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zm[mm][k] - ym[mm][k]);
         }
     }
     if (g == 0) red[6 * 16 + t] = 0ull;
@@ -454,29 +465,32 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
                     }
                 }
-                if (MIXED) {
-                    if (mixrow[cc]) {
-                        // mixed rows of step st (mpc_12state.cpp:600-630), second axis read from LDS
-                        const double *yin = vx + i_oth[cc];
-                        const double vxx = xt[1], axx = xt[2], vyy = yin[16], ayy = yin[32];
-                        const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
-                                               -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+            }
+            if (MIXED) {
+                // mixed rows of step m (mpc_12state.cpp:600-630) on the xt of both axes
 #pragma unroll
-                        for (int k = 0; k < 6; k++) {
-                            const double zr = alpha * zt6[k] + oma * zm[cc][k];
-                            const double s = zr + ym[cc][k];
-                            const double zn = clampd(s, -ovm[cc][k], ovm[cc][k]);
-                            ym[cc][k] = s - zn;
-                            zm[cc][k] = zn;
-                            if constexpr (CHK) {
-                                double d = P.rho_mx[k] * (zr - zn);
-                                if (ovm[cc][k] > kInfBound) d = 0.0;
-                                pin_n = fmax(pin_n, fabs(d));
-                                pin_l += ovm[cc][k] * fabs(d);
-                                lds[i_mx[cc] + k * 16] = d;
-                            } else {
-                                lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zn - ym[cc][k]);
-                            }
+                for (int mm = 0; mm < MAXM; mm++) {
+                    if (!mact[mm]) continue;
+                    const double *x0p = vx + i_mv[mm][0], *x1p = vx + i_mv[mm][1];
+                    const double vxx = x0p[16], axx = x0p[32], vyy = x1p[16], ayy = x1p[32];
+                    const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
+                                           -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const double bnd = k < 4 ? mvb[mm] : mam[mm];
+                        const double zr = alpha * zt6[k] + oma * zm[mm][k];
+                        const double s = zr + ym[mm][k];
+                        const double zn = clampd(s, -bnd, bnd);
+                        ym[mm][k] = s - zn;
+                        zm[mm][k] = zn;
+                        if constexpr (CHK) {
+                            double d = P.rho_mx[k] * (zr - zn);
+                            if (bnd > kInfBound) d = 0.0;
+                            pin_n = fmax(pin_n, fabs(d));
+                            pin_l += bnd * fabs(d);
+                            lds[i_mw[mm] + k * 16] = d;
+                        } else {
+                            lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zn - ym[mm][k]);
                         }
                     }
                 }
@@ -539,11 +553,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
 #pragma unroll
                 for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * yg[cc][k];
-                if (MIXED) {
-                    if (mixrow[cc]) {
+            }
+            if (MIXED) {
 #pragma unroll
-                        for (int k = 0; k < 6; k++) lds[i_mx[cc] + k * 16] = P.rho_mx[k] * ym[cc][k];
-                    }
+                for (int mm = 0; mm < MAXM; mm++) {
+                    if (!mact[mm]) continue;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * ym[mm][k];
                 }
             }
             __syncthreads();
@@ -615,20 +631,22 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         m_ax = fmax(m_ax, fabs(axv));
                         m_z = fmax(m_z, fabs(b));
                     }
-                    // ... mixed rows
-                    if (MIXED) {
-                        if (mixrow[cc]) {
-                            const double *yin = vx + i_oth[cc];
-                            const double vxx = x[cc][1], axx = x[cc][2], vyy = yin[16], ayy = yin[32];
-                            const double ax6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
-                                                   -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+                }
+            }
+            // ... mixed rows
+            if (MIXED) {
 #pragma unroll
-                            for (int k = 0; k < 6; k++) {
-                                m_rp = fmax(m_rp, fabs(ax6[k] - zm[cc][k]));
-                                m_ax = fmax(m_ax, fabs(ax6[k]));
-                                m_z = fmax(m_z, fabs(zm[cc][k]));
-                            }
-                        }
+                for (int mm = 0; mm < MAXM; mm++) {
+                    if (!mact[mm]) continue;
+                    const double *x0p = vx + i_mv[mm][0], *x1p = vx + i_mv[mm][1];
+                    const double vxx = x0p[16], axx = x0p[32], vyy = x1p[16], ayy = x1p[32];
+                    const double ax6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
+                                           -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        m_rp = fmax(m_rp, fabs(ax6[k] - zm[mm][k]));
+                        m_ax = fmax(m_ax, fabs(ax6[k]));
+                        m_z = fmax(m_z, fabs(zm[mm][k]));
                     }
                 }
             }
@@ -705,13 +723,18 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                                 a.warm[e0 + (size_t)k * a.ldw] = lds[i_bg[cc] + k * 16];
                                 a.warm[e0 + (size_t)(ncell * D + k) * a.ldw] = yg[cc][k];
                             }
-                            if (MIXED && ax == 0) {
-                                const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + st * 6) * a.ldw + inst;
+                        }
+                    }
+                    if (MIXED) {
 #pragma unroll
-                                for (int k = 0; k < 6; k++) {
-                                    a.warm[m0 + (size_t)k * a.ldw] = zm[cc][k];
-                                    a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw] = ym[cc][k];
-                                }
+                        for (int mm = 0; mm < MAXM; mm++) {
+                            if (!mact[mm]) continue;
+                            const int m = g + kStride * mm;
+                            const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + m * 6) * a.ldw + inst;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) {
+                                a.warm[m0 + (size_t)k * a.ldw] = zm[mm][k];
+                                a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw] = ym[mm][k];
                             }
                         }
                     }
@@ -725,11 +748,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                 for (int k = 0; k < D; k++)
                     lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (lds[i_bg[cc] + k * 16] - yg[cc][k]);
-                if (MIXED) {
-                    if (mixrow[cc]) {
+            }
+            if (MIXED) {
 #pragma unroll
-                        for (int k = 0; k < 6; k++) lds[i_mx[cc] + k * 16] = P.rho_mx[k] * (zm[cc][k] - ym[cc][k]);
-                    }
+                for (int mm = 0; mm < MAXM; mm++) {
+                    if (!mact[mm]) continue;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zm[mm][k] - ym[mm][k]);
                 }
             }
         }
