@@ -71,7 +71,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
 //   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
-template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -89,8 +89,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
 
     const int V0 = 0;
-    const int VX = P.separate_xt ? (n_int + S) * 16 : 0;
-    const int WEQ = (P.separate_xt ? 2 : 1) * (n_int + S) * 16;
+    const int VX = SEP ? (n_int + S) * 16 : 0;
+    const int WEQ = (SEP ? 2 : 1) * (n_int + S) * 16;
     const int WMX = WEQ + (ncell * D + D) * 16;
     const int ZERO = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);
     const int BGT = ZERO + 8 * 16;                                           // [NAX][D][16] -x0: l = u of the step-0 rows
@@ -311,19 +311,31 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // D[16 rows x 16 instances] += A[16 x 4] * B[4 x 16]: A = operator fragment (registers
         // when it fits, else streamed from L2 through a prefetch ring), B = rhs rows from LDS
         {
-            d4 acc0[MAXIT], acc1[PAIR ? MAXIT : 1];
+            // with a separate xt vector (SEP) an item's rows are stored as soon as they are done;
+            // otherwise xt overwrites the rhs and the stores wait for every wave's last read
+            auto store = [&](int grp, int rb, bool two, const d4 &c0, const d4 &c1) __attribute__((always_inline)) {
+                double *o0 = vx + (KSREG > 0 ? boff_r + rb * 256 : (P.grp_first[grp] * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15));
+                const int row0 = rb * 16 + (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[r * 64] = c0[r];
+                if (PAIR && two) {
+                    double *o1 = o0 + (size_t)nb * 16;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o1[r * 64] = c1[r];
+                }
+            };
+            d4 acc0[SEP ? 1 : MAXIT], acc1[(PAIR && !SEP) ? MAXIT : 1];
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
-                acc0[it] = (d4){0, 0, 0, 0};
-                if (PAIR) acc1[it] = (d4){0, 0, 0, 0};
                 if (it < nit) {
                     const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
                     const bool two = KSREG > 0 ? two_r : (PAIR && P.grp_cnt[grp] == 2);
                     const double *bp0 = v0 + (KSREG > 0 ? boff_r : (P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15));
                     const double *bp1 = bp0 + (size_t)nb * 16;
                     if constexpr (KSREG > 0) {
-                        // ks == KSREG here (host dispatch): all B operands are fetched before the
-                        // first MFMA and the chain has no branches
+                        // ks <= KSREG (host dispatch): all B operands are fetched before the first
+                        // MFMA and the chain has no branches; fragments past ks are zero and their B
+                        // rows are whatever finite values follow the block in LDS
                         auto run = [&](auto two_c) __attribute__((always_inline)) {
                             constexpr bool TWO = decltype(two_c)::value;
                             double bf0[KSREG], bf1[TWO ? KSREG : 1];
@@ -344,8 +356,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                                 if constexpr (TWO) c1[0] += mreg[kk] * bf1[kk];
 #endif
                             }
-                            acc0[0] = c0;
-                            if constexpr (PAIR) acc1[0] = c1;
+                            if constexpr (SEP) store(grp, rb, TWO, c0, c1);
+                            else { acc0[0] = c0; if constexpr (PAIR) acc1[0] = c1; }
                         };
                         if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
                     } else {
@@ -388,25 +400,20 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                                     }
                                 }
                             }
-                            acc0[it] = c0;
-                            if constexpr (PAIR) acc1[it] = c1;
+                            if constexpr (SEP) store(grp, rb, TWO, c0, c1);
+                            else { acc0[it] = c0; if constexpr (PAIR) acc1[it] = c1; }
                         };
                         if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
                     }
                 }
             }
-            if (!P.separate_xt) __syncthreads();
+            if constexpr (!SEP) {
+                __syncthreads();
 #pragma unroll
-            for (int it = 0; it < MAXIT; it++) {
-                if (it < nit) {
-                    const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
-                    double *o0 = vx + (KSREG > 0 ? boff_r + rb * 256 : (P.grp_first[grp] * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15));
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o0[r * 64] = acc0[it][r];
-                    if (PAIR && (KSREG > 0 ? two_r : P.grp_cnt[grp] == 2)) {
-                        double *o1 = o0 + (size_t)nb * 16;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) o1[r * 64] = acc1[it][r];
+                for (int it = 0; it < MAXIT; it++) {
+                    if (it < nit) {
+                        const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
+                        store(grp, rb, KSREG > 0 ? two_r : P.grp_cnt[grp] == 2, acc0[it], acc1[PAIR ? it : 0]);
                     }
                 }
             }
@@ -894,10 +901,10 @@ size_t admm_lds_bytes(const StageDev &P)
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves) * 16 * sizeof(double);
 }
 
-template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG>
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP>;
     const size_t lds_bytes = admm_lds_bytes(P);
     // the dynamic LDS limit of a kernel is per device and sticky: raise it when it has to grow
     static int lds_set[64] = {0};
@@ -922,21 +929,26 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     int needi = 0;
     for (int w = 0; w < P.nwaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
     if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
-    if (P.nwaves == 16) {
-        if (P.D == 2 && P.nax == 3 && !P.mixed && needc <= 1 && needi <= 1 && P.ks == 16)
-            return launch_admm_t<1024, 2, 3, false, 1, 1, true, 16>(P, a, s);
-        *why = "no 16-wave kernel variant for this stage";
-        return hipErrorInvalidValue;
-    }
+    // register-resident variants read 4 * KSREG B rows from the start of every block: they must stay
+    // inside the zero-initialised part of LDS
+    const int S = P.D + 1;
+    const int rows_init = (P.separate_xt ? 2 : 1) * (P.n_int + S) + ncell * P.D + P.D +
+                          (P.mixed ? (P.N + 1) * 6 + 6 : 0) + 8 + P.nax * P.D;
+    auto fits = [&](int ksreg) { return P.ks <= ksreg && (P.n_int - P.nb) + 4 * ksreg <= rows_init; };
+    if (P.nwaves != 8) { *why = "only 8-wave workgroups are compiled"; return hipErrorInvalidValue; }
+    const bool sep = P.separate_xt != 0;
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (needc <= 2 && needi <= 1 && P.ks == 16) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16>(P, a, s);
-        if (needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0>(P, a, s);
+        if (sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(P, a, s);
+        if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(P, a, s);
+        if (!sep && needc <= 8 && needi <= 4) return launch_admm_t<512, 2, 3, false, 8, 4, true, 0, false>(P, a, s);
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
-        if (needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0>(P, a, s);
-        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0>(P, a, s);
+        if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(P, a, s);
+        if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(P, a, s);
+        if (!sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false>(P, a, s);
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (needc <= 1 && needi <= 1 && P.ks == 24) return launch_admm_t<512, 3, 1, false, 1, 1, false, 24>(P, a, s);
-        if (needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0>(P, a, s);
+        if (sep && needc <= 1 && needi <= 1 && fits(24)) return launch_admm_t<512, 3, 1, false, 1, 1, false, 24, true>(P, a, s);
+        if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(P, a, s);
+        if (!sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 1, false, 4, 4, false, 0, false>(P, a, s);
     }
     *why = "horizon too long for the compiled kernel variants";
     return hipErrorInvalidValue;

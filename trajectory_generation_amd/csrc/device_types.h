@@ -10,7 +10,7 @@ constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2, TG_DEV_PRIMAL_INFEASIBLE 
 constexpr double kInfBound = 1e26;      // OSQP_INFTY * MIN_SCALING: bounds beyond it count as infinite
 constexpr double kDivisionTol = 1e-30;  // 1 / OSQP_INFTY
 constexpr int kMaxAxes = 3, kMaxSlots = 4;
-constexpr int kAdmmWaves = 16;          // most waves an ADMM workgroup has (StageDev::nwaves: 8 or 16)
+constexpr int kAdmmWaves = 8;           // waves of an ADMM workgroup
 constexpr int kMaxItems = 8;                                        // MFMA work items per wave
 constexpr int kRingDepth = 8;   // operator fragments (k steps) a wave keeps in flight from L2
 
@@ -21,7 +21,7 @@ constexpr int kRingDepth = 8;   // operator fragments (k steps) a wave keeps in 
 // (axis a, step i, slot k) = axis_base[a] + i*(D+1) + k.
 struct StageDev {
     int N, D, nax, mixed;        // horizon, chain order, axes, XY mixed rows present
-    int n_int, nb, nrb, ks;      // padded size of all blocks, block size, row blocks, k steps
+    int n_int, nb, nrb, ks;      // rows of all blocks, rows of one block (= block stride), 16-row blocks, k steps
     int ks_alloc;                // k steps stored per (operator, row block): ks + kRingDepth zero steps
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];

@@ -12,6 +12,7 @@
 
 namespace tg {
 hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why);
+size_t admm_lds_bytes(const StageDev &P);
 hipError_t launch_assemble(const AsmDev &P, const BatchArgs &a, double *q, double *l, double *u,
                            hipStream_t s);
 hipError_t launch_xy_bounds(int B, int ld, int N, double xy_max_vel, double xy_max_accel,
@@ -90,9 +91,8 @@ struct DevStage {
         if ((rc = upload(sp.asm_ov_mixed, &d_ovm))) return rc;
         const bool six = mdl.family == TG_FAM_6DOF, xy = mdl.family == TG_FAM_XY;
         dev.N = mdl.N; dev.D = sp.D; dev.nax = sp.nax; dev.mixed = mdl.n_mixed ? 1 : 0;
-        dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = sp.nb / 16; dev.ks = sp.nb / 4; dev.ks_alloc = dev.ks + kRingDepth;
+        dev.n_int = sp.n_int; dev.nb = sp.nb; dev.nrb = (sp.nb + 15) / 16; dev.ks = (sp.nb + 3) / 4; dev.ks_alloc = dev.ks + kRingDepth;
         dev.nwaves = 8;
-        if (const char *e = getenv("TG_ADMM_WAVES")) dev.nwaves = atoi(e) == 16 ? 16 : 8;   // development switch
         // groups of up to two adjacent blocks that share an operator
         dev.ngrp = 0;
         for (int b = 0; b < sp.nblk;) {
@@ -141,13 +141,11 @@ struct DevStage {
             }
         }
         for (int k = 0; k < 6; k++) { dev.rho_mx[k] = sp.rho_mx[k]; dev.ub_mx[k] = sp.ub_mx[k]; }
-        // a second on-chip vector for xt saves one barrier per block group; take it when two
-        // workgroups still fit a CU's 160 KiB of LDS
-        {
-            const int ncell = sp.nax * (mdl.N + 1);
-            size_t rows2 = (size_t)2 * sp.n_int + (size_t)ncell * sp.D + (dev.mixed ? (size_t)(mdl.N + 1) * 6 : 0);
-            dev.separate_xt = rows2 * 16 * 8 + 1024 <= 80 * 1024 ? 1 : 0;
-        }
+        // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
+        // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
+        // the iterates of the 16 instances still fit the 160 KiB of LDS
+        dev.separate_xt = 1;
+        if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.separate_xt = 0;
         dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
         dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
         adev.n = sp.n; adev.m = sp.m; adev.rows_per_block = 32;

@@ -60,7 +60,7 @@ struct StageProblem {
     int axis_base[kMaxAxes] = {0, 0, 0};
     std::vector<int> op_of_block;
     std::vector<int> var_ref;              // n_int -> reference variable or -1
-    std::vector<double> Mfrag;             // [nops][nb/16][nb/4 + kRingDepth][64]
+    std::vector<double> Mfrag;             // [nops][ceil(nb/16)][ceil(nb/4) + kRingDepth][64]
     double rho_eq = 0;
     double rho_box[kMaxAxes][kMaxSlots] = {}, lb[kMaxAxes][kMaxSlots] = {}, ub[kMaxAxes][kMaxSlots] = {};
     double rho_mx[6] = {0}, ub_mx[6] = {0};
@@ -238,7 +238,7 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
     sp.D = D; sp.nax = nax;
     sp.nblk = six ? 3 : 1;
     const int per_axis = S * (N + 1);
-    sp.nb = ((six ? per_axis : nax * per_axis) + 15) / 16 * 16;
+    sp.nb = six ? per_axis : nax * per_axis;   // rows of one block, also the stride between blocks
     sp.n_int = sp.nblk * sp.nb;
     for (int a = 0; a < nax; a++) sp.axis_base[a] = six ? a * sp.nb : a * per_axis;
     sp.var_ref.assign(sp.n_int, -1);
@@ -260,6 +260,8 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
         for (int j = 0; j < n; j++)
             if (blk_of[i] != blk_of[j] && K[(size_t)i * n + j] != 0.0) { err = "internal: axes are coupled"; return false; }
     // operators: blocks whose K sub-matrices coincide share one inverse
+    // reference variable of local row li of block b; rows past the block (MFMA padding) have none
+    auto vref = [&](int b, int li) -> int { return li < sp.nb ? sp.var_ref[b * sp.nb + li] : -1; };
     auto Kint = [&](int b, int i, int j) -> double {
         int ri = sp.var_ref[b * sp.nb + i], rj = sp.var_ref[b * sp.nb + j];
         return (ri >= 0 && rj >= 0) ? K[(size_t)ri * n + rj] : 0.0;
@@ -277,14 +279,14 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
     }
     sp.nops = (int)op_rep.size();
     // operator fragments: Mfrag[op][rb][kk][lane] = Kinv_block[rb*16 + (lane&15)][4*kk + (lane>>4)]
-    const int nrb = sp.nb / 16, ks = sp.nb / 4, ksa = ks + kRingDepth;   // zero steps: prefetch overrun
+    const int nrb = (sp.nb + 15) / 16, ks = (sp.nb + 3) / 4, ksa = ks + kRingDepth;   // zero steps: prefetch overrun
     sp.Mfrag.assign((size_t)sp.nops * nrb * ksa * 64, 0.0);
     for (int o = 0; o < sp.nops; o++) {
         const int b = op_rep[o];
         for (int rb = 0; rb < nrb; rb++)
             for (int kk = 0; kk < ks; kk++)
                 for (int lane = 0; lane < 64; lane++) {
-                    int ri = sp.var_ref[b * sp.nb + rb * 16 + (lane & 15)], rk = sp.var_ref[b * sp.nb + 4 * kk + (lane >> 4)];
+                    int ri = vref(b, rb * 16 + (lane & 15)), rk = vref(b, 4 * kk + (lane >> 4));
                     double v = (ri >= 0 && rk >= 0) ? sp.Kinv[(size_t)ri * n + rk] : 0.0;
                     sp.Mfrag[(((size_t)o * nrb + rb) * ksa + kk) * 64 + lane] = v;
                 }
