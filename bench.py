@@ -31,7 +31,7 @@ WORKLOADS = {
     "rollout_6dof_B8192_N20": ("6dof", 8192, 20, 5),
 }
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD at 2.4 GHz)
-FP64_MFMA_SUSTAINED_TFLOPS = 47.5   # what tools/microbench/mfma_f64_peak.hip sustains on the box (register-only MFMA chains)
+FP64_MFMA_SUSTAINED_TFLOPS = 75.7   # tools/microbench/mfma_valu_overlap.hip on the box: register-only MFMA, two chains per SIMD
 
 
 def flops_per_iteration(model, N):
