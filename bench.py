@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-3)
     ap.add_argument("--max-iter", type=int, default=4000, help="ADMM iteration budget per solve (OSQP default 4000)")
     ap.add_argument("--check", type=int, default=25, help="termination check interval (OSQP default 25)")
+    ap.add_argument("--grid-cap", type=int, default=0, help="most workgroups per solve (0: what the GPU holds at once, -1: one per tile of 16 instances)")
     ap.add_argument("--check-fine", type=int, default=None, help="check interval after the first check (0: OSQP's fixed interval)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
@@ -114,13 +115,15 @@ def main():
 
     model, B, N, seed_off = WORKLOADS[args.workload]
     if args.check_fine is None:
-        # 6-DOF open-loop batches: after the first check test every 5 iterations, so a tile of 16
-        # instances does not wait for the next multiple of 25.  Closed loop and the 12-state chain
-        # keep OSQP's interval: their iterates feed a next problem (next step's initial state, the
-        # XY bounds, the yaw reference), and iterates nearer the tolerance make more of those
-        # infeasible or slow to certify as such.
-        args.check_fine = 5 if args.workload.startswith("mpc_6dof") else 0
-    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check, check_fine=args.check_fine)
+        # One tile per CU (4096 instances): after the first check test every 5 iterations, so a
+        # tile of 16 instances does not wait for the next multiple of 25.  Batches of many tiles per
+        # CU refill their instance slots from the batch instead, no slot waits for its tile, and the
+        # cheaper schedule is OSQP's own.  Closed loop and the 12-state chain keep OSQP's interval
+        # as well: their iterates feed a next problem (next step's initial state, the XY bounds,
+        # the yaw reference), and iterates nearer the tolerance make more of those infeasible or
+        # slow to certify as such.
+        args.check_fine = 5 if args.workload == "mpc_6dof_B4096_N20" else 0
+    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check, check_fine=args.check_fine, grid_cap=args.grid_cap)
     first = rank * B                       # weak scaling: every rank owns its own slab of B instances
     if model == "6dof":
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts, device=local)
@@ -230,7 +233,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "model": None, "instances_per_gpu": B, "horizon_N": N,
-                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "rho": eng.rho if model == "6dof" else
+                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "grid_cap": args.grid_cap, "rho": eng.rho if model == "6dof" else
                    [eng.rho(k) for k in ("xy", "z", "yaw")], "parallelism": "instances sharded x%d" % world},
         "p50_batch_ms": float(np.median(lat)),
         "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),

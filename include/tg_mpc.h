@@ -89,6 +89,14 @@ typedef struct {
      * Earlier stops mean iterates that sit closer to the tolerance.  Default 0 = OSQP's fixed
      * interval. */
     int    check_fine;
+    /* Largest number of workgroups (tiles of 16 instance slots) a solve launches.  0: as many as
+     * the GPU holds at once.  When the batch has more tiles than that, a slot whose instance has
+     * terminated takes the next instance of the batch, so no slot waits for the slowest member of
+     * its tile; every instance keeps its own iteration count and check schedule, and its result
+     * does not depend on the batch around it.  Needs max_iter to be a multiple of
+     * check_termination and check_termination a multiple of check_fine (at most 32 times it);
+     * otherwise, or with a negative value, every tile gets a workgroup of its own. */
+    int    grid_cap;
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

@@ -387,6 +387,54 @@ def test_12state_failed_stage_gates_the_later_ones(tg, oracle):
     assert ok.sum() == B - 1 and np.abs(r["X"][ok] - ro["X"][ok]).max() < 1e-8
 
 
+@pytest.mark.parametrize("fine,cap", [(0, 1), (5, 1), (5, 3), (0, 4)])
+def test_slot_refill_is_bit_identical_6dof(tg, oracle, fine, cap):
+    """A grid smaller than the batch: instance slots take the next instance of the batch when
+    theirs terminates.  Every instance keeps its own iteration count and check schedule, so
+    solutions, statuses and iteration counts equal those of one workgroup per tile bit for bit,
+    cold and warm, with an infeasible instance in the batch; a sample is checked against the oracle."""
+    N, B = 20, 333
+    p, op = _p6_pair(tg, oracle, N=N)
+    x0, ref = oracle.synth_mpc6(21, N, 0.1, B)
+    x0[77, 3] = 50.0                                 # infeasible: certified at its own multiple of 25
+    x1 = x0 + 0.03; ref1 = ref + 0.01
+    res = []
+    for gc in (-1, cap):
+        eng = tg.BatchedMPC6(p, tg.make_opts(check_fine=fine, grid_cap=gc))
+        res.append((eng.solve_host(x0, ref, warm=True), eng.solve_host(x1, ref1, warm=True)))
+    for k in range(2):
+        a, b = res[0][k], res[1][k]
+        np.testing.assert_array_equal(a["status"], b["status"])
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+        ok = a["status"] == 1
+        assert ok.sum() == B - 1 and a["status"][77] == -3
+        assert np.abs(a["X"][ok] - b["X"][ok]).max() == 0.0 and np.abs(a["U"][ok] - b["U"][ok]).max() == 0.0
+    assert len(np.unique(res[0][0]["iters"])) > 1     # slots did finish at different times
+    oracle.match_rho_classes(eng.rho_rows())
+    idx = np.arange(300, 333)                         # instances that entered through the queue
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0, check_fine=fine), x0[idx], ref[idx])
+    np.testing.assert_array_equal(res[1][0]["iters"][idx], ro["iters"])
+    assert np.abs(res[1][0]["X"][idx] - ro["X"]).max() < 1e-9
+
+
+def test_slot_refill_is_bit_identical_12state(tg, oracle):
+    """The same for the three chained stages, with an instance whose XY stage is infeasible: its
+    yaw stage is skipped when the slot reaches it through the queue, too."""
+    N, B, first = 20, 80, 1040                       # holds instance 1092 of the benchmark batch
+    x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B, first)
+    res = []
+    for gc in (-1, 2):
+        eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(grid_cap=gc))
+        res.append(eng.solve_host(x12, ref12))
+    a, b = res
+    np.testing.assert_array_equal(a["status"], b["status"])
+    np.testing.assert_array_equal(a["iters"], b["iters"])
+    assert tuple(a["status"][52]) == (1, -3, -10) and a["iters"][52][2] == 0
+    ok = (a["status"] == 1).all(1)
+    assert ok.sum() == B - 1
+    assert np.array_equal(a["X"][ok], b["X"][ok]) and np.array_equal(a["U"][ok], b["U"][ok])
+
+
 # ---------------------------------------------------------------- full benchmark sizes: properties
 def test_config2_full_size_properties(tg):
     """mpc_6dof, 4096 instances, N = 20: size-independent checks on every instance --

@@ -80,11 +80,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int tid = threadIdx.x;
     const int t = tid & 15, g = tid >> 4;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int inst = blockIdx.x * kTileDev + t;
-    // an instance whose upstream stage did not reach "solved" is not attempted
-    // (MPC12STATE::mpcLoop returns at the first failing stage, mpc_12state.cpp:1374-1453)
-    const bool gated = inst < a.B && a.gate && a.gate[inst] != TG_DEV_SOLVED;
-    const bool valid = inst < a.B && !gated;
+    // The 16 columns of the tile are slots: a slot starts on instance blockIdx.x * 16 + t and, when
+    // the grid is smaller than the batch, takes the next unassigned instance from a.queue each
+    // time its instance terminates.  Every instance runs its own iteration count and its own
+    // schedule of checks, so its result does not depend on what shares the tile with it.
+    // Slot bookkeeping that only the checks need lives in LDS (slot_inst, slot_start, and the
+    // slot's ||q||_inf in red[6]) to keep the iteration loop's registers for the iterates.
+    bool exhausted = a.queue == nullptr;    // no further instance to take
+    bool done = false;
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
 
@@ -97,6 +100,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int CTAB = BGT + NAX * D * 16;                                     // [NAX][S][3] rho, lb, ub
     unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
     double *rsum = (double *)(red + 9 * 16);                                        // [waves][16] partial sums
+    int *slot_inst = (int *)(rsum + kWaves * 16);                                   // [16] instance of each slot
+    int *slot_start = slot_inst + 16;                                               // [16] tile iteration it began at
     double *v0 = lds + V0, *vx = lds + VX;
 
     const double sigma = P.sigma, alpha = P.alpha, oma = 1.0 - P.alpha;
@@ -136,74 +141,23 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     int i_mx[MIXED ? MAXC : 1];     // absolute index of the step's mixed-row w (or ZERO)
     bool axis0[MIXED ? MAXC : 1];
 
-    double qn = 0.0;
 #pragma unroll
     for (int cc = 0; cc < MAXC; cc++) {
         const int c = g + kStride * cc;
         const bool act = c < ncell;
         const int ax = act ? c / N1 : 0;
         const int st = act ? c - ax * N1 : 0;
-        int abase = 0, x0r = 0, refoff = 0;
-        double qw = 0.0;
+        int abase = 0;
 #pragma unroll
-        for (int k = 0; k < NAX; k++)
-            if (ax == k) { abase = P.axis_base[k]; x0r = P.x0_row[k]; refoff = P.ref_off[k]; qw = P.qw[k]; }
+        for (int k = 0; k < NAX; k++) if (ax == k) abase = P.axis_base[k];
         i_var[cc] = act ? (abase + st * S) * 16 + t : n_int * 16 + t;
         i_prev[cc] = (act && st > 0) ? VX + i_var[cc] - S * 16 : ZERO + t;
         i_wnext[cc] = (act && st < N) ? WEQ + ((c + 1) * D) * 16 + t : ZERO + t;
         i_ct[cc] = CTAB + ax * S * 3;
         i_bg[cc] = (act && st == 0) ? BGT + ax * D * 16 + t : ZERO + t;
-        double zg0[D], b0[D];
-        q[cc] = 0.0;
-#pragma unroll
-        for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; yb[cc][k] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < D; k++) { zg0[k] = 0.0; yg[cc][k] = 0.0; b0[k] = 0.0; }
         if (MIXED) {
             i_mx[cc] = (act && st >= 1) ? WMX + st * 6 * 16 + t : ZERO + t;
             axis0[cc] = ax == 0;
-            hiv[cc][0] = lds[i_ct[cc] + 1 * 3 + 2];
-            hiv[cc][1] = lds[i_ct[cc] + 2 * 3 + 2];
-        }
-        if (act && valid) {
-            q[cc] = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
-            qn = fmax(qn, fabs(q[cc]));
-            if (st == 0) {
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    b0[k] = -a.x0[(size_t)(x0r + k * P.x0_slot) * a.ld + inst];
-                    lds[i_bg[cc] + k * 16] = b0[k];
-                }
-            }
-            if (MIXED && st >= 1) {
-                const size_t r0 = (size_t)(6 * (st - 1) + 3 * ax) * a.ov_ld + inst;
-                hiv[cc][0] = a.ov_box[r0 + (size_t)a.ov_ld];
-                hiv[cc][1] = a.ov_box[r0 + (size_t)2 * a.ov_ld];
-            }
-            if (a.warm_in) {
-                const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
-#pragma unroll
-                for (int k = 0; k < S; k++) {
-                    x[cc][k] = a.warm[w0 + (size_t)k * a.ldw];
-                    zb[cc][k] = a.warm[w0 + (size_t)(n_int + k) * a.ldw];
-                    yb[cc][k] = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw];
-                }
-                const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
-#pragma unroll
-                for (int k = 0; k < D; k++) {
-                    zg0[k] = a.warm[e0 + (size_t)k * a.ldw];
-                    yg[cc][k] = a.warm[e0 + (size_t)(ncell * D + k) * a.ldw];
-                }
-            }
-        }
-        // w of the cell's rows for the first rhs (unused slots write the spare rows at the end)
-        const int cw = act ? c : ncell;
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg0[k] - yg[cc][k]);
-            // the first projection relaxes with the starting z (zero, or the previous solve's):
-            // alpha zt + (1-alpha) z0 + y = alpha zt + (1-alpha) b + [y + (1-alpha)(z0 - b)]
-            yg[cc][k] += oma * (zg0[k] - b0[k]);
         }
     }
     if (MIXED) {
@@ -215,31 +169,119 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             i_mw[mm] = mact[mm] ? WMX + m * 6 * 16 + t : WMX + N1 * 6 * 16 + t;
             i_mv[mm][0] = (P.axis_base[0] + ms * S) * 16 + t;
             i_mv[mm][1] = (P.axis_base[1] + ms * S) * 16 + t;
-            mvb[mm] = 0.0; mam[mm] = 0.0;
+        }
+    }
+
+    // Start the slot's instance `inst` (fresh slots only; the others keep their state): iterates
+    // zero or the previous solve's, q, the step-0 bound, the per-instance boxes, and the w of the
+    // first rhs.  Returns the slot's part of ||q||_inf.
+    auto load = [&](const bool fresh, const int inst) __attribute__((always_inline)) -> double {
+        // an instance whose upstream stage did not reach "solved" is not attempted
+        // (MPC12STATE::mpcLoop returns at the first failing stage, mpc_12state.cpp:1374-1453)
+        const bool gated = fresh && inst < a.B && a.gate && a.gate[inst] != TG_DEV_SOLVED;
+        const bool valid = fresh && inst < a.B && !gated;
+        double qmax = 0.0;
+        if (!fresh) return qmax;
 #pragma unroll
-            for (int k = 0; k < 6; k++) { zm[mm][k] = 0.0; ym[mm][k] = 0.0; }
-            if (mact[mm] && valid) {
-                mvb[mm] = a.ov_mixed[(size_t)(6 * (m - 1) + 0) * a.ov_ld + inst];
-                mam[mm] = a.ov_mixed[(size_t)(6 * (m - 1) + 4) * a.ov_ld + inst];
+        for (int cc = 0; cc < MAXC; cc++) {
+            const int c = g + kStride * cc;
+            const bool act = c < ncell;
+            const int ax = act ? c / N1 : 0;
+            const int st = act ? c - ax * N1 : 0;
+            int abase = 0, x0r = 0, refoff = 0;
+            double qw = 0.0;
+#pragma unroll
+            for (int k = 0; k < NAX; k++)
+                if (ax == k) { abase = P.axis_base[k]; x0r = P.x0_row[k]; refoff = P.ref_off[k]; qw = P.qw[k]; }
+            double zg0[D], b0[D];
+            q[cc] = 0.0;
+#pragma unroll
+            for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; yb[cc][k] = 0.0; }
+#pragma unroll
+            for (int k = 0; k < D; k++) { zg0[k] = 0.0; yg[cc][k] = 0.0; b0[k] = 0.0; }
+            if (MIXED) {
+                hiv[cc][0] = lds[i_ct[cc] + 1 * 3 + 2];
+                hiv[cc][1] = lds[i_ct[cc] + 2 * 3 + 2];
+            }
+            if (act && valid) {
+                q[cc] = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
+                qmax = fmax(qmax, fabs(q[cc]));
+                if (st == 0) {
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        b0[k] = -a.x0[(size_t)(x0r + k * P.x0_slot) * a.ld + inst];
+                        lds[i_bg[cc] + k * 16] = b0[k];
+                    }
+                }
+                if (MIXED && st >= 1) {
+                    const size_t r0 = (size_t)(6 * (st - 1) + 3 * ax) * a.ov_ld + inst;
+                    hiv[cc][0] = a.ov_box[r0 + (size_t)a.ov_ld];
+                    hiv[cc][1] = a.ov_box[r0 + (size_t)2 * a.ov_ld];
+                }
                 if (a.warm_in) {
-                    const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + m * 6) * a.ldw + inst;
+                    const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        zm[mm][k] = a.warm[m0 + (size_t)k * a.ldw];
-                        ym[mm][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw];
+                    for (int k = 0; k < S; k++) {
+                        x[cc][k] = a.warm[w0 + (size_t)k * a.ldw];
+                        zb[cc][k] = a.warm[w0 + (size_t)(n_int + k) * a.ldw];
+                        yb[cc][k] = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw];
+                    }
+                    const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        zg0[k] = a.warm[e0 + (size_t)k * a.ldw];
+                        yg[cc][k] = a.warm[e0 + (size_t)(ncell * D + k) * a.ldw];
                     }
                 }
             }
+            // w of the cell's rows for the first rhs (unused cells write the spare rows at the end)
+            const int cw = act ? c : ncell;
 #pragma unroll
-            for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zm[mm][k] - ym[mm][k]);
+            for (int k = 0; k < D; k++) {
+                lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg0[k] - yg[cc][k]);
+                // the first projection relaxes with the starting z (zero, or the previous solve's):
+                // alpha zt + (1-alpha) z0 + y = alpha zt + (1-alpha) b + [y + (1-alpha)(z0 - b)]
+                yg[cc][k] += oma * (zg0[k] - b0[k]);
+            }
         }
+        if (MIXED) {
+#pragma unroll
+            for (int mm = 0; mm < MAXM; mm++) {
+                const int m = g + kStride * mm;
+                mvb[mm] = 0.0; mam[mm] = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { zm[mm][k] = 0.0; ym[mm][k] = 0.0; }
+                if (mact[mm] && valid) {
+                    mvb[mm] = a.ov_mixed[(size_t)(6 * (m - 1) + 0) * a.ov_ld + inst];
+                    mam[mm] = a.ov_mixed[(size_t)(6 * (m - 1) + 4) * a.ov_ld + inst];
+                    if (a.warm_in) {
+                        const size_t m0 = (size_t)(3 * n_int + 2 * ncell * D + m * 6) * a.ldw + inst;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            zm[mm][k] = a.warm[m0 + (size_t)k * a.ldw];
+                            ym[mm][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zm[mm][k] - ym[mm][k]);
+            }
+        }
+        done = !valid;
+        if (gated && g == 0) {
+            if (a.status) a.status[inst] = TG_DEV_UNSOLVED;
+            if (a.iters) a.iters[inst] = 0;
+        }
+        return qmax;
+    };
+    {
+        const int inst0 = blockIdx.x * kTileDev + t;
+        double qf = load(true, inst0);
+        if (g == 0) { red[6 * 16 + t] = 0ull; slot_inst[t] = inst0; slot_start[t] = 0; }
+        __syncthreads();
+        qf = wave_gmax(qf);
+        if ((lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
     }
-    if (g == 0) red[6 * 16 + t] = 0ull;
-    __syncthreads();
-    qn = wave_gmax(qn);
-    if ((lane >> 4) == 0) lds_max(&red[6 * 16 + t], qn);
-    __syncthreads();
-    qn = __longlong_as_double((long long)red[6 * 16 + t]);
 
     const int nit = P.wi_cnt[wave];
     double mreg[KSREG > 0 ? KSREG : 1];
@@ -256,14 +298,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         }
     }
 
-    bool done = !valid;
-    if (gated && g == 0) {
-        if (a.status) a.status[inst] = TG_DEV_UNSOLVED;
-        if (a.iters) a.iters[inst] = 0;
-    }
-    const int max_iter = P.max_iter, check = P.check;
+    const int max_iter = P.max_iter, check = P.check, fine = P.check_fine;
     const double eps_pinf = P.eps_prim_inf;
-    if (__syncthreads_and(done ? 1 : 0)) return;   // no instance of this tile is to be solved
+    if (__syncthreads_and((done && exhausted) ? 1 : 0)) return;   // nothing to solve in this tile
 
     // One ADMM iteration.  CHK marks an iteration that is followed by a termination check: it
     // also needs the step delta_y = y+ - y of every row for OSQP's primal infeasibility test.
@@ -273,6 +310,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     double part[MAXC][S];
     double pin_n = 0.0, pin_l = 0.0;
     auto step = [&](auto chk_c) __attribute__((always_inline)) {
+        // The iterates must not depend on whether this is a checking iteration (a slot meets them
+        // at different points of its run depending on its neighbours): every rounding is written
+        // out, and the compiler may not fuse differently in the two instantiations.
+#pragma clang fp contract(off)
         constexpr bool CHK = decltype(chk_c)::value;
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
 #pragma unroll
@@ -288,23 +329,25 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             if (MIXED) {
                 const double *wm = lds + i_mx[cc];
                 const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                const double ca = axis0[cc] ? s3 : 0.5, cb = axis0[cc] ? 0.5 : s3, sg = axis0[cc] ? 1.0 : -1.0;
-                mixc[1] = ca * (w0 + sg * w1) + cb * (w2 - sg * w3);
-                mixc[2] = s2 * (w4 + sg * w5);
+                // axis 0: s3 (w0 + w1) + (w2 - w3) / 2, axis 1: (w0 - w1) / 2 + s3 (w2 + w3); selecting
+                // the sums keeps the coefficients compile-time constants instead of per-lane registers
+                const bool a0 = axis0[cc];
+                mixc[1] = __builtin_fma(s3, a0 ? w0 + w1 : w2 + w3, 0.5 * (a0 ? w2 - w3 : w0 - w1));
+                mixc[2] = s2 * (a0 ? w4 + w5 : w4 - w5);
             }
             double *out = v0 + i_var[cc];
             const double *ct = lds + i_ct[cc];
 #pragma unroll
             for (int l = 0; l < D; l++) {
-                double acc = sigma * x[cc][l] + ct[l * 3] * (zb[cc][l] - yb[cc][l]) - wo[l];
+                double acc = __builtin_fma(ct[l * 3], zb[cc][l] - yb[cc][l], sigma * x[cc][l]) - wo[l];
                 if (l == 0) acc -= q[cc];
 #pragma unroll
-                for (int k = 0; k <= l; k++) acc += chain_coef<D>(k, l, dt, c2) * wn[k];
+                for (int k = 0; k <= l; k++) acc = __builtin_fma(chain_coef<D>(k, l, dt, c2), wn[k], acc);
                 if (MIXED && l >= 1) acc += mixc[l];
                 out[l * 16] = acc;
             }
             // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
-            out[D * 16] = sigma * x[cc][D] + ct[D * 3] * (zb[cc][D] - yb[cc][D]) + dt * wn[D - 1];
+            out[D * 16] = __builtin_fma(ct[D * 3], zb[cc][D] - yb[cc][D], __builtin_fma(dt, wn[D - 1], sigma * x[cc][D]));
         }
         __syncthreads();
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
@@ -434,8 +477,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 // variables and their box rows
 #pragma unroll
                 for (int k = 0; k < S; k++) {
-                    x[cc][k] = alpha * xt[k] + oma * x[cc][k];
-                    const double zr = alpha * xt[k] + oma * zb[cc][k];
+                    x[cc][k] = __builtin_fma(alpha, xt[k], oma * x[cc][k]);
+                    const double zr = __builtin_fma(alpha, xt[k], oma * zb[cc][k]);
                     const double s = zr + yb[cc][k];
                     double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
                     if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
@@ -456,10 +499,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 for (int k = 0; k < D; k++) {
                     double zt = -xt[k];
 #pragma unroll
-                    for (int l = k; l < D; l++) zt += chain_coef<D>(k, l, dt, c2) * xp[l];
-                    if (k == D - 1) zt += dt * xp[D];
+                    for (int l = k; l < D; l++) zt = __builtin_fma(chain_coef<D>(k, l, dt, c2), xp[l], zt);
+                    if (k == D - 1) zt = __builtin_fma(dt, xp[D], zt);
                     const double b = lds[i_bg[cc] + k * 16];
-                    const double zr = alpha * zt + oma * b;
+                    const double zr = __builtin_fma(alpha, zt, oma * b);
                     const double s = zr + yg[cc][k];
                     yg[cc][k] = s - b;
                     if constexpr (CHK) {
@@ -480,12 +523,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     if (!mact[mm]) continue;
                     const double *x0p = vx + i_mv[mm][0], *x1p = vx + i_mv[mm][1];
                     const double vxx = x0p[16], axx = x0p[32], vyy = x1p[16], ayy = x1p[32];
-                    const double zt6[6] = {s3 * vxx + 0.5 * vyy, s3 * vxx - 0.5 * vyy, 0.5 * vxx + s3 * vyy,
-                                           -0.5 * vxx + s3 * vyy, s2 * axx + s2 * ayy, s2 * axx - s2 * ayy};
+                    const double hx = 0.5 * vxx, hy = 0.5 * vyy, sa = s2 * axx, sb = s2 * ayy;   // halves are exact
+                    const double zt6[6] = {__builtin_fma(s3, vxx, hy), __builtin_fma(s3, vxx, -hy), __builtin_fma(s3, vyy, hx),
+                                           __builtin_fma(s3, vyy, -hx), sa + sb, sa - sb};
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
                         const double bnd = k < 4 ? mvb[mm] : mam[mm];
-                        const double zr = alpha * zt6[k] + oma * zm[mm][k];
+                        const double zr = __builtin_fma(alpha, zt6[k], oma * zm[mm][k]);
                         const double s = zr + ym[mm][k];
                         const double zn = clampd(s, -bnd, bnd);
                         ym[mm][k] = s - zn;
@@ -505,20 +549,32 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         }
     };
 
-    for (int iter = 0; iter < max_iter;) {
-        // iterations up to the next check: at `check`, then every `check_fine` (or every `check`
-        // when check_fine is 0), and at max_iter
-        const int gap = (P.check_fine > 0 && iter >= check) ? P.check_fine : check;
-        const int burst = min(gap, max_iter - iter);
+    // Checks come at `check`, then every `check_fine` (or every `check` when check_fine is 0), and
+    // at max_iter, counted from the start of each slot's instance.  Slots are only refilled at
+    // checks, and the host enables refilling only when max_iter is a multiple of check and check
+    // a multiple of check_fine, so the tile's checks coincide with every slot's own.
+    // The infeasibility certificate is tested where OSQP's own schedule has a check (multiples of
+    // `check`, and the last iteration); the finer checks in between only test convergence.
+    // phase_mask: which residues of (tile iteration / check_fine) mod (check / check_fine) are a
+    // multiple of `check` for some live slot.
+    const bool refill = a.queue != nullptr;
+    const int nphase = fine > 0 ? max(check / fine, 1) : 1;
+    unsigned phase_mask = 1u;
+    for (int iter = 0;;) {
+        const int gap = (fine > 0 && iter >= check) ? fine : check;
+        const int burst = refill ? gap : min(gap, max_iter - iter);
         for (int i = 1; i < burst; i++) {
             step(std::false_type{});
             __syncthreads();
         }
         iter += burst;
-        // the infeasibility certificate is tested where OSQP's own schedule has a check (multiples
-        // of `check`, and the last iteration); the finer checks in between only test convergence
-        const bool full = P.check_fine <= 0 || iter % check == 0 || iter == max_iter;
+        const bool full = fine <= 0 || (refill ? ((phase_mask >> ((iter / fine) % nphase)) & 1u) != 0
+                                               : (iter % check == 0 || iter == max_iter));
         if (full) step(std::true_type{}); else step(std::false_type{});
+        const int local = iter - slot_start[t];    // iterations of the slot's own instance
+        const bool last = local == max_iter;
+        const bool eligible = local >= check || last;
+        const bool sfull = full && (fine <= 0 || local % check == 0 || last);
         // -------------------------------------------------------- termination check
         {
             __syncthreads();
@@ -532,9 +588,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (MIXED) {
                     const double *wm = lds + i_mx[cc];
                     const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                    const double ca = axis0[cc] ? s3 : 0.5, cb = axis0[cc] ? 0.5 : s3, sg = axis0[cc] ? 1.0 : -1.0;
-                    mixc[1] = ca * (w0 + sg * w1) + cb * (w2 - sg * w3);
-                    mixc[2] = s2 * (w4 + sg * w5);
+                    // axis 0: s3 (w0 + w1) + (w2 - w3) / 2, axis 1: (w0 - w1) / 2 + s3 (w2 + w3); selecting
+                    // the sums keeps the coefficients compile-time constants instead of per-lane registers
+                    const bool a0 = axis0[cc];
+                    mixc[1] = s3 * (a0 ? w0 + w1 : w2 + w3) + 0.5 * (a0 ? w2 - w3 : w0 - w1);
+                    mixc[2] = s2 * (a0 ? w4 + w5 : w4 - w5);
                 }
 #pragma unroll
                 for (int l = 0; l < D; l++) {
@@ -588,9 +646,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     if (MIXED) {
                         const double *wm = lds + i_mx[cc];
                         const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                        const double ca = axis0[cc] ? s3 : 0.5, cb = axis0[cc] ? 0.5 : s3, sg = axis0[cc] ? 1.0 : -1.0;
-                        mixc[1] = ca * (w0 + sg * w1) + cb * (w2 - sg * w3);
-                        mixc[2] = s2 * (w4 + sg * w5);
+                        const bool a0 = axis0[cc];
+                        mixc[1] = s3 * (a0 ? w0 + w1 : w2 + w3) + 0.5 * (a0 ? w2 - w3 : w0 - w1);
+                        mixc[2] = s2 * (a0 ? w4 + w5 : w4 - w5);
                     }
                     // dual residual P x + q + A' y on the state slots
 #pragma unroll
@@ -682,15 +740,17 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             m_px = __longlong_as_double((long long)red[4 * 16 + t]);
             m_aty = __longlong_as_double((long long)red[5 * 16 + t]);
             const double eps_p = P.eps_abs + P.eps_rel * fmax(m_ax, m_z);
+            const double qn = __longlong_as_double((long long)red[6 * 16 + t]);
             const double eps_d = P.eps_abs + P.eps_rel * fmax(fmax(m_px, m_aty), qn);
-            const bool conv = (m_rp < eps_p) && (m_rd < eps_d);
+            const bool conv = eligible && (m_rp < eps_p) && (m_rd < eps_d);
             // OSQP's certificate of primal infeasibility (is_primal_infeasible, only tried while
             // the primal residual is above its tolerance): delta_y, projected on the polar of the
             // recession cone of [l, u], separates the constraint set from the range of A
-            const bool pinf = full && !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
+            const bool pinf = sfull && eligible && !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
                               pin_l < -eps_pinf * pin_n && m_atdy < eps_pinf * pin_n;
-            if (!done && (conv || pinf || iter == max_iter)) {
+            if (!done && (conv || pinf || last)) {
                 done = true;
+                const int inst = slot_inst[t];
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
                 // is written for an infeasible instance
                 for (int cc = 0; cc < (conv || !pinf ? MAXC : 0); cc++) {
@@ -705,7 +765,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
                 if (g == 0) {
                     if (a.status) a.status[inst] = conv ? TG_DEV_SOLVED : (pinf ? TG_DEV_PRIMAL_INFEASIBLE : TG_DEV_MAX_ITER);
-                    if (a.iters) a.iters[inst] = iter;
+                    if (a.iters) a.iters[inst] = local;
                     if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.ld + inst] = m_rd; }
                 }
                 if (a.warm_out) {
@@ -747,7 +807,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                 }
             }
-            if (__syncthreads_and(done ? 1 : 0)) break;
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
@@ -764,8 +823,34 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zm[mm][k] - ym[mm][k]);
                 }
             }
+            // slots whose instance has terminated take the next unassigned one
+            const bool need = done && !exhausted;
+            if (__syncthreads_or(need ? 1 : 0)) {
+                int *next = (int *)rsum;
+                if (need && g == 0) {
+                    const int ni = a.queue_base + atomicAdd(a.queue, 1);
+                    next[t] = ni < a.B ? ni : -1;
+                    red[6 * 16 + t] = 0ull;
+                }
+                __syncthreads();
+                bool fresh = false;
+                const int ni = need ? next[t] : -1;
+                if (need) {
+                    if (ni < 0) exhausted = true; else fresh = true;
+                }
+                double qf = load(fresh, ni);
+                qf = wave_gmax(qf);
+                if (fresh && (lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
+                if (fresh && g == 0) { slot_inst[t] = ni; slot_start[t] = iter; }
+                if (fine > 0) {
+                    const int st0 = fresh ? iter : slot_start[t];
+                    phase_mask = (unsigned)__syncthreads_or(done ? 0 : (int)(1u << ((st0 / fine) % nphase)));
+                } else {
+                    __syncthreads();
+                }
+            }
+            if (__syncthreads_and((done && exhausted) ? 1 : 0)) break;
         }
-        __syncthreads();
     }
 }
 
@@ -898,7 +983,7 @@ size_t admm_lds_bytes(const StageDev &P)
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
                   (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D;
-    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves) * 16 * sizeof(double);
+    return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves + 1) * 16 * sizeof(double);
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP>
@@ -916,8 +1001,41 @@ static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) lds_set[dev] = (int)lds_bytes;
     }
-    const int grid = (a.B + kTileDev - 1) / kTileDev;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, s, P, a);
+    const int ntiles = (a.B + kTileDev - 1) / kTileDev;
+    int grid = ntiles;
+    BatchArgs b = a;
+    b.queue = nullptr;
+    b.queue_base = 0;
+    // A grid no larger than what the device holds at once, its slots refilled from a queue, keeps
+    // every slot busy until the batch runs out; a tile per workgroup makes each tile wait for its
+    // slowest instance.  The kernel's slot schedule needs the checks aligned (see admm_kernel).
+    const bool aligned = P.check > 0 && P.max_iter % P.check == 0 &&
+                         (P.check_fine <= 0 || (P.check % P.check_fine == 0 && P.check / P.check_fine <= 32));
+    if (a.queue_mem && aligned) {
+        int cap = a.grid_cap;
+        if (cap <= 0) {
+            static int resident[64] = {0}, resident_lds[64] = {0};
+            if (dev < 0 || dev >= 64 || resident[dev] == 0 || resident_lds[dev] != (int)lds_bytes) {
+                int per_cu = 0, cus = 0;
+                e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kern, NT, lds_bytes);
+                if (e != hipSuccess) return e;
+                e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                if (e != hipSuccess) return e;
+                cap = (per_cu > 0 ? per_cu : 1) * (cus > 0 ? cus : 1);
+                if (dev >= 0 && dev < 64) { resident[dev] = cap; resident_lds[dev] = (int)lds_bytes; }
+            } else {
+                cap = resident[dev];
+            }
+        }
+        if (ntiles > cap) {
+            grid = cap;
+            b.queue = a.queue_mem;
+            b.queue_base = grid * kTileDev;
+            e = hipMemsetAsync(a.queue_mem, 0, sizeof(int), s);
+            if (e != hipSuccess) return e;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds_bytes, s, P, b);
     return hipGetLastError();
 }
 

@@ -66,6 +66,13 @@ struct BatchArgs {
     double *res;             // optional [2][ld]: primal / dual residual at exit
     int warm_in, warm_out;
     double *warm;            // [warm_rows][ldw] iterates kept between calls
+    // Work queue for grids smaller than the batch: *queue counts the instances handed out beyond
+    // the first queue_base (= 16 per workgroup launched); null when every tile has a workgroup.
+    // launch_admm fills both in from queue_mem.
+    int *queue;
+    int queue_base;
+    int *queue_mem;          // one int of device memory owned by the stage (may be null)
+    int grid_cap;            // 0: as many workgroups as fit on the device at once; > 0: at most this many
 };
 
 } // namespace tg

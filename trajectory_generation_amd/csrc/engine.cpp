@@ -71,6 +71,8 @@ struct DevStage {
     StageDev dev{};
     AsmDev adev{};
     double *d_Mfrag = nullptr;
+    int *d_queue = nullptr;   // ticket counter of the kernel's instance queue
+    int grid_cap = 0;
     double *d_qw = nullptr, *d_lt = nullptr, *d_ut = nullptr;
     int32_t *d_qrr = nullptr, *d_x0r = nullptr, *d_ovb = nullptr, *d_ovm = nullptr;
     // warm-start iterates of the instance slots
@@ -82,6 +84,8 @@ struct DevStage {
         if (!build_stage(mdl, rho, o.sigma, o.rho_scale, sp, err)) return fail(TG_E_NUMERIC, err);
         int rc;
         if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
+        HIP_TRY(hipMalloc((void **)&d_queue, sizeof(int)));
+        grid_cap = o.grid_cap;
         if ((rc = upload(sp.q_w, &d_qw))) return rc;
         if ((rc = upload(sp.l_t, &d_lt))) return rc;
         if ((rc = upload(sp.u_t, &d_ut))) return rc;
@@ -155,7 +159,7 @@ struct DevStage {
     }
     void release()
     {
-        hipFree(d_Mfrag);
+        hipFree(d_Mfrag); hipFree(d_queue);
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
         hipFree(d_ovm); hipFree(d_warm);
     }
@@ -186,6 +190,8 @@ struct DevStage {
             a.warm_in = (warm_valid && warm_B >= a.B) ? 1 : 0;
             a.warm_out = 1;
         }
+        a.queue_mem = grid_cap >= 0 ? d_queue : nullptr;
+        a.grid_cap = grid_cap;
         const char *why = "";
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_timing) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, s)); }
@@ -264,7 +270,7 @@ extern "C" {
 void tg_default_opts(tg_solver_opts *o)
 {
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
-    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0;
+    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0; o->grid_cap = 0;
     for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }

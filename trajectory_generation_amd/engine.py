@@ -16,11 +16,13 @@ def _torch():
 
 
 def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000,
-              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0):
+              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0, grid_cap=0):
     """rho <= 0 and rho_scale entries of 0 select the engine's built-in choices; rho_scale is
     (position, velocity, acceleration, input) multipliers of rho on the box rows;
     eps_prim_inf = 0 switches the primal infeasibility test off; check_fine > 0: after the first
-    check (iteration check_termination) test every check_fine iterations, 0: OSQP's fixed interval."""
+    check (iteration check_termination) test every check_fine iterations, 0: OSQP's fixed interval;
+    grid_cap: most workgroups a solve launches (0: what the GPU holds at once, < 0: one per tile of
+    16 instances); a smaller grid refills its instance slots from the rest of the batch."""
     o = capi.SolverOpts()
     capi.load().tg_default_opts(C.byref(o))
     o.rho_scale[:] = [float(v) for v in rho_scale]
@@ -28,6 +30,7 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
     o.eps_abs, o.eps_rel, o.max_iter, o.check_termination = eps_abs, eps_rel, max_iter, check_termination
     o.eps_prim_inf = eps_prim_inf
     o.check_fine = check_fine
+    o.grid_cap = grid_cap
     return o
 
 
