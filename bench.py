@@ -43,10 +43,11 @@ def flops_per_iteration(model, N):
     return 2 * ((8 * N + 6) ** 2 + 2 * (4 * N + 3) ** 2)
 
 
-def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=5):
+def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=5, smoothing=False, stress=False):
     """Reference CPU path restated (OSQP algorithm with its default settings, one instance at a
     time on one core, as the reference runs it) on a bounded sample of the same workload."""
     from oracle import oracle as O
+    from trajectory_generation_amd.synth import stress as synth_stress
     O.build()
     sample = 384 if model == "6dof" else 256
     if N >= 50:
@@ -61,13 +62,17 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=5)
         else:
             O.match_rho_classes(rho_rows)                # the engine's fixed per-class step sizes
         if model == "6dof":
-            p = O.mpc6_params(N=N)
+            p = O.mpc6_params(N=N, enable_control_smoothing=smoothing)
             x0, ref = O.synth_mpc6(SEED + seed_off, N, 0.1, sample)
+            if stress:
+                x0, ref = synth_stress(model, x0, ref, N)
             s = mk() if mk else fixed(rho)
             t = time.perf_counter(); r = O.mpc6_batch(p, s, x0, ref); dt = time.perf_counter() - t
         else:
-            p = O.mpc12_params(N=N)
+            p = O.mpc12_params(N=N, enable_control_smoothing=smoothing)
             x0, ref = O.synth_mpc12(SEED + seed_off, N, 0.1, sample)
+            if stress:
+                x0, ref = synth_stress(model, x0, ref, N)
             s = mk() if mk else {k: fixed(rho[i]) for i, k in enumerate(("xy", "z", "yaw"))}
             t = time.perf_counter(); r = O.mpc12_batch(p, s, x0, ref); dt = time.perf_counter() - t
         out[kind] = dict(value=sample / dt, iters_mean=float(np.mean(r["iters"])), solved=float(r["n_ok"]) / sample)
@@ -93,6 +98,8 @@ def main():
     ap.add_argument("--check-fine", type=int, default=None, help="check interval after the first check (0: OSQP's fixed interval)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
+    ap.add_argument("--smoothing", action="store_true", help="input smoothing term on (the test mains' setting; config/mpc.yaml has it off)")
+    ap.add_argument("--stress", action="store_true", help="every instance in the geometry of the reference's test main: target 40 m above, limits active")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -126,11 +133,13 @@ def main():
     opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check, check_fine=args.check_fine, grid_cap=args.grid_cap)
     first = rank * B                       # weak scaling: every rank owns its own slab of B instances
     if model == "6dof":
-        eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts, device=local)
+        eng = tg.BatchedMPC6(tg.mpc6_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
         x0, ref = synth.mpc6(SEED + seed_off, N, 0.1, B, first)
     else:
-        eng = tg.BatchedMPC12(tg.mpc12_params(N=N), opts, device=local)
+        eng = tg.BatchedMPC12(tg.mpc12_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
         x0, ref = synth.mpc12(SEED + seed_off, N, 0.1, B, first)
+    if args.stress:
+        x0, ref = synth.stress(model, x0, ref, N)
     buf = eng.alloc(B)
     buf["x0"][:, :B] = torch.from_numpy(np.ascontiguousarray(x0.T)).cuda()
     buf["ref"][:, :B] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()
@@ -233,7 +242,8 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "model": None, "instances_per_gpu": B, "horizon_N": N,
-                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "grid_cap": args.grid_cap, "rho": eng.rho if model == "6dof" else
+                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "grid_cap": args.grid_cap,
+                   "smoothing": bool(args.smoothing), "inputs": "stress" if args.stress else "seeded", "rho": eng.rho if model == "6dof" else
                    [eng.rho(k) for k in ("xy", "z", "yaw")], "parallelism": "instances sharded x%d" % world},
         "p50_batch_ms": float(np.median(lat)),
         "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),
@@ -249,7 +259,8 @@ def main():
     }
     del out["config"]["model"]
     if not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(model, N, seed_off, args.eps, out["config"]["rho"], eng.rho_rows(), args.check, args.check_fine)
+        out["cpu_baseline"] = cpu_baseline(model, N, seed_off, args.eps, out["config"]["rho"], eng.rho_rows(), args.check, args.check_fine,
+                                           args.smoothing, args.stress)
         if closed:
             out["cpu_baseline"]["sample"] += "; cold-started single solves of the same problems (the closed-loop GPU " \
                                              "steps are warm-started)"

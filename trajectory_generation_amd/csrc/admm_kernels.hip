@@ -316,38 +316,56 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma clang fp contract(off)
         constexpr bool CHK = decltype(chk_c)::value;
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
+        // Cells are handled in groups of G: every LDS read of the group is issued before its first
+        // LDS write.  The compiler cannot tell that the regions do not overlap, so a write between
+        // two cells' reads would serialise their latencies.  Variants with many cells per thread
+        // have no registers to spare for it.
+        constexpr int G = MAXC <= 2 ? MAXC : 1;
 #pragma unroll
-        for (int cc = 0; cc < ((TG_ABLATE & 2) ? 0 : MAXC); cc++) {
-            const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
-            double wn[D], wo[D];
+        for (int c0 = 0; c0 < ((TG_ABLATE & 2) ? 0 : MAXC); c0 += G) {
+            double wn[G][D], wo[G][D], rr[G][S], mixc[G][3];
 #pragma unroll
-            for (int k = 0; k < D; k++) {
-                wo[k] = lds[WEQ + (cw * D + k) * 16 + t];
-                wn[k] = lds[i_wnext[cc] + k * 16];
+            for (int j = 0; j < G; j++) {
+                const int cc = c0 + j;
+                if (cc >= MAXC) continue;
+                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
+#pragma unroll
+                for (int k = 0; k < D; k++) {
+                    wo[j][k] = lds[WEQ + (cw * D + k) * 16 + t];
+                    wn[j][k] = lds[i_wnext[cc] + k * 16];
+                }
+                if constexpr (G > 1) {
+#pragma unroll
+                    for (int k = 0; k < S; k++) rr[j][k] = lds[i_ct[cc] + k * 3];
+                }
+                mixc[j][0] = mixc[j][1] = mixc[j][2] = 0.0;
+                if (MIXED) {
+                    const double *wm = lds + i_mx[cc];
+                    const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
+                    // axis 0: s3 (w0 + w1) + (w2 - w3) / 2, axis 1: (w0 - w1) / 2 + s3 (w2 + w3); selecting
+                    // the sums keeps the coefficients compile-time constants instead of per-lane registers
+                    const bool a0 = axis0[cc];
+                    mixc[j][1] = __builtin_fma(s3, a0 ? w0 + w1 : w2 + w3, 0.5 * (a0 ? w2 - w3 : w0 - w1));
+                    mixc[j][2] = s2 * (a0 ? w4 + w5 : w4 - w5);
+                }
             }
-            double mixc[3] = {0.0, 0.0, 0.0};
-            if (MIXED) {
-                const double *wm = lds + i_mx[cc];
-                const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                // axis 0: s3 (w0 + w1) + (w2 - w3) / 2, axis 1: (w0 - w1) / 2 + s3 (w2 + w3); selecting
-                // the sums keeps the coefficients compile-time constants instead of per-lane registers
-                const bool a0 = axis0[cc];
-                mixc[1] = __builtin_fma(s3, a0 ? w0 + w1 : w2 + w3, 0.5 * (a0 ? w2 - w3 : w0 - w1));
-                mixc[2] = s2 * (a0 ? w4 + w5 : w4 - w5);
-            }
-            double *out = v0 + i_var[cc];
-            const double *ct = lds + i_ct[cc];
 #pragma unroll
-            for (int l = 0; l < D; l++) {
-                double acc = __builtin_fma(ct[l * 3], zb[cc][l] - yb[cc][l], sigma * x[cc][l]) - wo[l];
-                if (l == 0) acc -= q[cc];
+            for (int j = 0; j < G; j++) {
+                const int cc = c0 + j;
+                if (cc >= MAXC) continue;
+                double *out = v0 + i_var[cc];
 #pragma unroll
-                for (int k = 0; k <= l; k++) acc = __builtin_fma(chain_coef<D>(k, l, dt, c2), wn[k], acc);
-                if (MIXED && l >= 1) acc += mixc[l];
-                out[l * 16] = acc;
+                for (int l = 0; l < D; l++) {
+                    double acc = __builtin_fma(G > 1 ? rr[j][l] : lds[i_ct[cc] + l * 3], zb[cc][l] - yb[cc][l], sigma * x[cc][l]) - wo[j][l];
+                    if (l == 0) acc -= q[cc];
+#pragma unroll
+                    for (int k = 0; k <= l; k++) acc = __builtin_fma(chain_coef<D>(k, l, dt, c2), wn[j][k], acc);
+                    if (MIXED && l >= 1) acc += mixc[j][l];
+                    out[l * 16] = acc;
+                }
+                // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
+                out[D * 16] = __builtin_fma(G > 1 ? rr[j][D] : lds[i_ct[cc] + D * 3], zb[cc][D] - yb[cc][D], __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
             }
-            // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
-            out[D * 16] = __builtin_fma(ct[D * 3], zb[cc][D] - yb[cc][D], __builtin_fma(dt, wn[D - 1], sigma * x[cc][D]));
         }
         __syncthreads();
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
@@ -465,54 +483,86 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- relaxation, projection, dual
         if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; }
         {
+            // the mixed rows' reads come first, for the same reason as the grouping of the cells
+            double mv[MAXM][4];
+            if (MIXED) {
 #pragma unroll
-            for (int cc = 0; cc < ((TG_ABLATE & 4) ? 0 : MAXC); cc++) {
-                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
-                const double *xin = vx + i_var[cc];
-                const double *xpr = lds + i_prev[cc];
-                const double *ct = lds + i_ct[cc];
-                double xt[S], xp[S];
-#pragma unroll
-                for (int k = 0; k < S; k++) { xt[k] = xin[k * 16]; xp[k] = xpr[k * 16]; }
-                // variables and their box rows
-#pragma unroll
-                for (int k = 0; k < S; k++) {
-                    x[cc][k] = __builtin_fma(alpha, xt[k], oma * x[cc][k]);
-                    const double zr = __builtin_fma(alpha, xt[k], oma * zb[cc][k]);
-                    const double s = zr + yb[cc][k];
-                    double lo = ct[k * 3 + 1], hi = ct[k * 3 + 2];
-                    if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
-                    const double zn = clampd(s, lo, hi);
-                    if constexpr (CHK) {
-                        double d = ct[k * 3] * (zr - zn);
-                        if (hi > kInfBound) d = lo < -kInfBound ? 0.0 : fmin(d, 0.0);
-                        else if (lo < -kInfBound) d = fmax(d, 0.0);
-                        pin_n = fmax(pin_n, fabs(d));
-                        pin_l += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
-                        part[cc][k] = d;
-                    }
-                    yb[cc][k] = s - zn;
-                    zb[cc][k] = zn;
+                for (int mm = 0; mm < MAXM; mm++) {
+                    const double *x0p = vx + i_mv[mm][0], *x1p = vx + i_mv[mm][1];
+                    mv[mm][0] = x0p[16]; mv[mm][1] = x0p[32]; mv[mm][2] = x1p[16]; mv[mm][3] = x1p[32];
                 }
-                // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
+            }
 #pragma unroll
-                for (int k = 0; k < D; k++) {
-                    double zt = -xt[k];
+            for (int c0 = 0; c0 < ((TG_ABLATE & 4) ? 0 : MAXC); c0 += G) {
+                double xt[G][S], xp[G][S], bnd[G][S][2], rr[CHK ? G : 1][S], bg[G][D];
 #pragma unroll
-                    for (int l = k; l < D; l++) zt = __builtin_fma(chain_coef<D>(k, l, dt, c2), xp[l], zt);
-                    if (k == D - 1) zt = __builtin_fma(dt, xp[D], zt);
-                    const double b = lds[i_bg[cc] + k * 16];
-                    const double zr = __builtin_fma(alpha, zt, oma * b);
-                    const double s = zr + yg[cc][k];
-                    yg[cc][k] = s - b;
-                    if constexpr (CHK) {
-                        const double d = rho_eq * (zr - b);
-                        pin_n = fmax(pin_n, fabs(d));
-                        pin_l += b * d;
-                        part[cc][k] -= d;
-                        lds[WEQ + (cw * D + k) * 16 + t] = d;
-                    } else {
-                        lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+                for (int j = 0; j < G; j++) {
+                    const int cc = c0 + j;
+                    if (cc >= MAXC) continue;
+                    const double *xin = vx + i_var[cc];
+                    const double *xpr = lds + i_prev[cc];
+                    const double *ct = lds + i_ct[cc];
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        xt[j][k] = xin[k * 16]; xp[j][k] = xpr[k * 16];
+                        if constexpr (G > 1) {
+                            if (MIXED && (k == 1 || k == 2)) { bnd[j][k][1] = hiv[cc][k - 1]; bnd[j][k][0] = -bnd[j][k][1]; }
+                            else { bnd[j][k][0] = ct[k * 3 + 1]; bnd[j][k][1] = ct[k * 3 + 2]; }
+                            if constexpr (CHK) rr[j][k] = ct[k * 3];
+                        }
+                    }
+                    if constexpr (G > 1) {
+#pragma unroll
+                        for (int k = 0; k < D; k++) bg[j][k] = lds[i_bg[cc] + k * 16];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int cc = c0 + j;
+                    if (cc >= MAXC) continue;
+                    const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
+                    // variables and their box rows
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        x[cc][k] = __builtin_fma(alpha, xt[j][k], oma * x[cc][k]);
+                        const double zr = __builtin_fma(alpha, xt[j][k], oma * zb[cc][k]);
+                        const double s = zr + yb[cc][k];
+                        double lo, hi;   // a single cell at a time reads its constants where they are used
+                        if constexpr (G > 1) { lo = bnd[j][k][0]; hi = bnd[j][k][1]; }
+                        else if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
+                        else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+                        const double zn = clampd(s, lo, hi);
+                        if constexpr (CHK) {
+                            double d = (G > 1 ? rr[j][k] : lds[i_ct[cc] + k * 3]) * (zr - zn);
+                            if (hi > kInfBound) d = lo < -kInfBound ? 0.0 : fmin(d, 0.0);
+                            else if (lo < -kInfBound) d = fmax(d, 0.0);
+                            pin_n = fmax(pin_n, fabs(d));
+                            pin_l += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
+                            part[cc][k] = d;
+                        }
+                        yb[cc][k] = s - zn;
+                        zb[cc][k] = zn;
+                    }
+                    // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
+#pragma unroll
+                    for (int k = 0; k < D; k++) {
+                        double zt = -xt[j][k];
+#pragma unroll
+                        for (int l = k; l < D; l++) zt = __builtin_fma(chain_coef<D>(k, l, dt, c2), xp[j][l], zt);
+                        if (k == D - 1) zt = __builtin_fma(dt, xp[j][D], zt);
+                        const double b = G > 1 ? bg[j][k] : lds[i_bg[cc] + k * 16];
+                        const double zr = __builtin_fma(alpha, zt, oma * b);
+                        const double s = zr + yg[cc][k];
+                        yg[cc][k] = s - b;
+                        if constexpr (CHK) {
+                            const double d = rho_eq * (zr - b);
+                            pin_n = fmax(pin_n, fabs(d));
+                            pin_l += b * d;
+                            part[cc][k] -= d;
+                            lds[WEQ + (cw * D + k) * 16 + t] = d;
+                        } else {
+                            lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+                        }
                     }
                 }
             }
@@ -521,24 +571,23 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                 for (int mm = 0; mm < MAXM; mm++) {
                     if (!mact[mm]) continue;
-                    const double *x0p = vx + i_mv[mm][0], *x1p = vx + i_mv[mm][1];
-                    const double vxx = x0p[16], axx = x0p[32], vyy = x1p[16], ayy = x1p[32];
+                    const double vxx = mv[mm][0], axx = mv[mm][1], vyy = mv[mm][2], ayy = mv[mm][3];
                     const double hx = 0.5 * vxx, hy = 0.5 * vyy, sa = s2 * axx, sb = s2 * ayy;   // halves are exact
                     const double zt6[6] = {__builtin_fma(s3, vxx, hy), __builtin_fma(s3, vxx, -hy), __builtin_fma(s3, vyy, hx),
                                            __builtin_fma(s3, vyy, -hx), sa + sb, sa - sb};
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        const double bnd = k < 4 ? mvb[mm] : mam[mm];
+                        const double bd = k < 4 ? mvb[mm] : mam[mm];
                         const double zr = __builtin_fma(alpha, zt6[k], oma * zm[mm][k]);
                         const double s = zr + ym[mm][k];
-                        const double zn = clampd(s, -bnd, bnd);
+                        const double zn = clampd(s, -bd, bd);
                         ym[mm][k] = s - zn;
                         zm[mm][k] = zn;
                         if constexpr (CHK) {
                             double d = P.rho_mx[k] * (zr - zn);
-                            if (bnd > kInfBound) d = 0.0;
+                            if (bd > kInfBound) d = 0.0;
                             pin_n = fmax(pin_n, fabs(d));
-                            pin_l += bnd * fabs(d);
+                            pin_l += bd * fabs(d);
                             lds[i_mw[mm] + k * 16] = d;
                         } else {
                             lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zn - ym[mm][k]);

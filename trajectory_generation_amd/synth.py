@@ -68,6 +68,25 @@ def mpc12(seed, N, dt, B, first=0):
     return x, ref.reshape(B, -1)
 
 
+def stress(model, x0, ref, N):
+    """The geometry of the reference's 12-state test main on every instance of a batch
+    (test/test_mpc_12state.cpp:146-167): the vehicle starts at rest at its drawn position and
+    the target hovers 4 m ahead in x, 0.5 m in y and 40 m above -- further than the horizon can
+    cover, so velocity, acceleration and input limits are active along most of it."""
+    nx = 6 if model == "6dof" else 12
+    pos = (0, 1, 2) if model == "6dof" else (0, 3, 6)
+    x0 = x0.copy()
+    keep = np.zeros(nx, dtype=bool)
+    keep[list(pos)] = True
+    if model != "6dof":
+        keep[9] = True                       # yaw
+    x0[:, ~keep] = 0.0
+    r = np.zeros((x0.shape[0], N + 1, nx))
+    for c, off in zip(pos, (4.0, 0.5, 40.0)):
+        r[:, :, c] = (x0[:, c] + off)[:, None]
+    return x0, r.reshape(x0.shape[0], -1)
+
+
 def shard(B, rank, world):
     """Contiguous slab [first, first + count) of a batch of B instances for `rank` of `world`."""
     base, rem = divmod(B, world)
