@@ -36,11 +36,19 @@ FP64_MFMA_SUSTAINED_TFLOPS = 75.7   # tools/microbench/mfma_valu_overlap.hip on 
 
 def flops_per_iteration(model, N):
     """Dense reduced-KKT apply actually executed per ADMM iteration and instance: 2 * size^2
-    per independent block (6-DOF: three per-axis blocks of 3N+2; the monolithic 9N+6 form of
-    the reference would be 3x this)."""
+    per block (6-DOF: three per-axis blocks of 3N+2, the monolithic 9N+6 form of the reference
+    would be 3x this; 12-state: Z and yaw one block of 4N+3 each, XY two blocks of 4N+3 -- the
+    sum and the difference of its two interchangeable axes -- where the monolithic 8N+6 form
+    would be 2x that)."""
     if model == "6dof":
         return 3 * 2 * (3 * N + 2) ** 2
-    return 2 * ((8 * N + 6) ** 2 + 2 * (4 * N + 3) ** 2)
+    return sum(stage_flops_12state(N))
+
+
+def stage_flops_12state(N):
+    """Executed flops per iteration and instance of the stages in status-row order (z, xy, yaw)."""
+    blk = 2 * (4 * N + 3) ** 2
+    return [blk, 2 * blk, blk]
 
 
 def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=5, smoothing=False, stress=False):
@@ -221,8 +229,7 @@ def main():
     launches_per_step = stages
     flops_launch = float(iters.sum()) * flops_per_iteration(model, N) / launches_per_step
     if model != "6dof":   # per-stage sizes differ: weight the stage iteration counts
-        n_stage = {0: 4 * N + 3, 1: 8 * N + 6, 2: 4 * N + 3}
-        flops_launch = sum(float(iters[k].sum()) * 2 * n_stage[k] ** 2 for k in range(3)) / 3
+        flops_launch = sum(float(iters[k].sum()) * f for k, f in enumerate(stage_flops_12state(N))) / 3
     # average admm_kernel launch over the timed region: event time / launches (the other kernels of a
     # step -- xy bounds, yaw reference, plant, shift -- are < 1 % of it); the per-launch event pairs
     # taken after the timed region are reported beside it

@@ -13,7 +13,7 @@ def run(model, N, B, iters=200, reps=5, check=25):
         flops = 3 * 2 * (3 * N + 2) ** 2
     else:
         eng = tg.BatchedMPC12(tg.mpc12_params(N=N), opts); x0, ref = synth.mpc12(1, N, 0.1, B)
-        flops = 2 * ((8 * N + 6) ** 2 + 2 * (4 * N + 3) ** 2)
+        flops = 4 * 2 * (4 * N + 3) ** 2
     buf = eng.alloc(B)
     buf["x0"][:, :B] = torch.from_numpy(np.ascontiguousarray(x0.T)).cuda()
     buf["ref"][:, :B] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()

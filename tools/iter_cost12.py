@@ -16,11 +16,11 @@ good.solve(buf); torch.cuda.synchronize()          # a real upstream solution in
 eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters,
                                                          check_termination=iters, eps_prim_inf=0.0))
 X = buf["X"].clone()
-for stage, n in (("z", 4 * N + 3), ("xy", 8 * N + 6), ("yaw", 4 * N + 3)):
+for stage, n, blocks in (("z", 4 * N + 3, 1), ("xy", 4 * N + 3, 2), ("yaw", 4 * N + 3, 1)):
     buf["X"].copy_(X)
     eng.solve_stage(stage, buf); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(5):
         eng.solve_stage(stage, buf)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
-    print(f"12state N={N} B={B} stage {stage}: {dt/iters*1e6:.2f} us per tile-iteration, {B*iters*2*n*n/dt/1e12:.2f} TFLOP/s", flush=True)
+    print(f"12state N={N} B={B} stage {stage}: {dt/iters*1e6:.2f} us per tile-iteration, {B*iters*blocks*2*n*n/dt/1e12:.2f} TFLOP/s", flush=True)

@@ -90,6 +90,15 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     bool done = false;
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
+    // Cell cc of thread group g: linear cell index ax * (N+1) + st, or ncell for an unused slot.
+    // The two-axis stage (XY) keeps both cells of a step in one thread (cc even: axis 0, odd: axis
+    // 1): the linear solve works on their sum and difference (see the rhs phase), and the step's
+    // mixed rows need both.
+    auto cell_of = [&](int cc) __attribute__((always_inline)) -> int {
+        if (MIXED) { const int st = g + kStride * (cc >> 1); return st <= N ? (cc & 1) * N1 + st : ncell; }
+        const int c = g + kStride * cc;
+        return c < ncell ? c : ncell;
+    };
 
     const int V0 = 0;
     const int VX = SEP ? (n_int + S) * 16 : 0;
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 
 #pragma unroll
     for (int cc = 0; cc < MAXC; cc++) {
-        const int c = g + kStride * cc;
+        const int c = cell_of(cc);
         const bool act = c < ncell;
         const int ax = act ? c / N1 : 0;
         const int st = act ? c - ax * N1 : 0;
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         if (!fresh) return qmax;
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
-            const int c = g + kStride * cc;
+            const int c = cell_of(cc);
             const bool act = c < ncell;
             const int ax = act ? c / N1 : 0;
             const int st = act ? c - ax * N1 : 0;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // LDS write.  The compiler cannot tell that the regions do not overlap, so a write between
         // two cells' reads would serialise their latencies.  Variants with many cells per thread
         // have no registers to spare for it.
-        constexpr int G = MAXC <= 2 ? MAXC : 1;
+        constexpr int G = MIXED ? 2 : (MAXC <= 2 ? MAXC : 1);
 #pragma unroll
         for (int c0 = 0; c0 < ((TG_ABLATE & 2) ? 0 : MAXC); c0 += G) {
             double wn[G][D], wo[G][D], rr[G][S], mixc[G][3];
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             for (int j = 0; j < G; j++) {
                 const int cc = c0 + j;
                 if (cc >= MAXC) continue;
-                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
+                const int cw = cell_of(cc);
 #pragma unroll
                 for (int k = 0; k < D; k++) {
                     wo[j][k] = lds[WEQ + (cw * D + k) * 16 + t];
@@ -349,11 +358,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     mixc[j][2] = s2 * (a0 ? w4 + w5 : w4 - w5);
                 }
             }
+            double racc[G][S];
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 const int cc = c0 + j;
                 if (cc >= MAXC) continue;
-                double *out = v0 + i_var[cc];
 #pragma unroll
                 for (int l = 0; l < D; l++) {
                     double acc = __builtin_fma(G > 1 ? rr[j][l] : lds[i_ct[cc] + l * 3], zb[cc][l] - yb[cc][l], sigma * x[cc][l]) - wo[j][l];
@@ -361,10 +370,29 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k <= l; k++) acc = __builtin_fma(chain_coef<D>(k, l, dt, c2), wn[j][k], acc);
                     if (MIXED && l >= 1) acc += mixc[j][l];
-                    out[l * 16] = acc;
+                    racc[j][l] = acc;
                 }
                 // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
-                out[D * 16] = __builtin_fma(G > 1 ? rr[j][D] : lds[i_ct[cc] + D * 3], zb[cc][D] - yb[cc][D], __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
+                racc[j][D] = __builtin_fma(G > 1 ? rr[j][D] : lds[i_ct[cc] + D * 3], zb[cc][D] - yb[cc][D], __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
+            }
+            if constexpr (MIXED) {
+                // The two axes are interchangeable in K = P + sigma I + A' rho A (same weights, same
+                // step sizes, and the mixed rows map onto themselves when x and y swap), so
+                // K^-1 = [[E, F], [F, E]] and  xt_x + xt_y = (E + F)(r_x + r_y),
+                // xt_x - xt_y = (E - F)(r_x - r_y): two products of half the size.  The axis-0 rows
+                // carry the sum, the axis-1 rows the difference; the operators hold (E +- F) / 2.
+                double *o0 = v0 + i_var[c0], *o1 = v0 + i_var[c0 + 1];
+#pragma unroll
+                for (int l = 0; l < S; l++) { o0[l * 16] = racc[0][l] + racc[1][l]; o1[l * 16] = racc[0][l] - racc[1][l]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < G; j++) {
+                    const int cc = c0 + j;
+                    if (cc >= MAXC) continue;
+                    double *out = v0 + i_var[cc];
+#pragma unroll
+                    for (int l = 0; l < S; l++) out[l * 16] = racc[j][l];
+                }
             }
         }
         __syncthreads();
@@ -483,15 +511,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- relaxation, projection, dual
         if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; }
         {
-            // the mixed rows' reads come first, for the same reason as the grouping of the cells
-            double mv[MAXM][4];
-            if (MIXED) {
-#pragma unroll
-                for (int mm = 0; mm < MAXM; mm++) {
-                    const double *x0p = vx + i_mv[mm][0], *x1p = vx + i_mv[mm][1];
-                    mv[mm][0] = x0p[16]; mv[mm][1] = x0p[32]; mv[mm][2] = x1p[16]; mv[mm][3] = x1p[32];
-                }
-            }
 #pragma unroll
             for (int c0 = 0; c0 < ((TG_ABLATE & 4) ? 0 : MAXC); c0 += G) {
                 double xt[G][S], xp[G][S], bnd[G][S][2], rr[CHK ? G : 1][S], bg[G][D];
@@ -516,11 +535,20 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         for (int k = 0; k < D; k++) bg[j][k] = lds[i_bg[cc] + k * 16];
                     }
                 }
+                if constexpr (MIXED) {
+                    // the rows hold (xt_x + xt_y) / 2 and (xt_x - xt_y) / 2 of the step (and of the
+                    // previous one): back to the two axes
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        const double u = xt[0][k], v = xt[1][k], up = xp[0][k], vp = xp[1][k];
+                        xt[0][k] = u + v; xt[1][k] = u - v; xp[0][k] = up + vp; xp[1][k] = up - vp;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < G; j++) {
                     const int cc = c0 + j;
                     if (cc >= MAXC) continue;
-                    const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
+                    const int cw = cell_of(cc);
                     // variables and their box rows
 #pragma unroll
                     for (int k = 0; k < S; k++) {
@@ -565,32 +593,31 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         }
                     }
                 }
-            }
-            if (MIXED) {
-                // mixed rows of step m (mpc_12state.cpp:600-630) on the xt of both axes
+                if constexpr (MIXED) {
+                    // mixed rows of the step (mpc_12state.cpp:600-630) on the xt of both axes
+                    const int mm = c0 >> 1;
+                    if (mact[mm]) {
+                        const double vxx = xt[0][1], axx = xt[0][2], vyy = xt[1][1], ayy = xt[1][2];
+                        const double hx = 0.5 * vxx, hy = 0.5 * vyy, sa = s2 * axx, sb = s2 * ayy;   // halves are exact
+                        const double zt6[6] = {__builtin_fma(s3, vxx, hy), __builtin_fma(s3, vxx, -hy), __builtin_fma(s3, vyy, hx),
+                                               __builtin_fma(s3, vyy, -hx), sa + sb, sa - sb};
 #pragma unroll
-                for (int mm = 0; mm < MAXM; mm++) {
-                    if (!mact[mm]) continue;
-                    const double vxx = mv[mm][0], axx = mv[mm][1], vyy = mv[mm][2], ayy = mv[mm][3];
-                    const double hx = 0.5 * vxx, hy = 0.5 * vyy, sa = s2 * axx, sb = s2 * ayy;   // halves are exact
-                    const double zt6[6] = {__builtin_fma(s3, vxx, hy), __builtin_fma(s3, vxx, -hy), __builtin_fma(s3, vyy, hx),
-                                           __builtin_fma(s3, vyy, -hx), sa + sb, sa - sb};
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        const double bd = k < 4 ? mvb[mm] : mam[mm];
-                        const double zr = __builtin_fma(alpha, zt6[k], oma * zm[mm][k]);
-                        const double s = zr + ym[mm][k];
-                        const double zn = clampd(s, -bd, bd);
-                        ym[mm][k] = s - zn;
-                        zm[mm][k] = zn;
-                        if constexpr (CHK) {
-                            double d = P.rho_mx[k] * (zr - zn);
-                            if (bd > kInfBound) d = 0.0;
-                            pin_n = fmax(pin_n, fabs(d));
-                            pin_l += bd * fabs(d);
-                            lds[i_mw[mm] + k * 16] = d;
-                        } else {
-                            lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zn - ym[mm][k]);
+                        for (int k = 0; k < 6; k++) {
+                            const double bd = k < 4 ? mvb[mm] : mam[mm];
+                            const double zr = __builtin_fma(alpha, zt6[k], oma * zm[mm][k]);
+                            const double s = zr + ym[mm][k];
+                            const double zn = clampd(s, -bd, bd);
+                            ym[mm][k] = s - zn;
+                            zm[mm][k] = zn;
+                            if constexpr (CHK) {
+                                double d = P.rho_mx[k] * (zr - zn);
+                                if (bd > kInfBound) d = 0.0;
+                                pin_n = fmax(pin_n, fabs(d));
+                                pin_l += bd * fabs(d);
+                                lds[i_mw[mm] + k * 16] = d;
+                            } else {
+                                lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zn - ym[mm][k]);
+                            }
                         }
                     }
                 }
@@ -661,7 +688,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // x -> VX, y of the dynamics / mixed rows -> WEQ / WMX (restored below)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
+                const int cw = cell_of(cc);
                 double *xo = vx + i_var[cc];
 #pragma unroll
                 for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
@@ -680,7 +707,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int c = g + kStride * cc;
+                const int c = cell_of(cc);
                 if (c < ncell) {
                     const int ax = c / N1, st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
@@ -803,7 +830,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
                 // is written for an infeasible instance
                 for (int cc = 0; cc < (conv || !pinf ? MAXC : 0); cc++) {
-                    const int c = g + kStride * cc;
+                    const int c = cell_of(cc);
                     if (c < ncell) {
                         const int ax = c / N1, st = c - ax * N1;
                         const double *xs = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
@@ -820,7 +847,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (a.warm_out) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
-                        const int c = g + kStride * cc;
+                        const int c = cell_of(cc);
                         if (c < ncell) {
                             const int ax = c / N1, st = c - ax * N1;
                             int abase = 0;
@@ -859,7 +886,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = (g + kStride * cc) < ncell ? g + kStride * cc : ncell;
+                const int cw = cell_of(cc);
 #pragma unroll
                 for (int k = 0; k < D; k++)
                     lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (lds[i_bg[cc] + k * 16] - yg[cc][k]);
@@ -1092,7 +1119,8 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
 {
     const int ncell = P.nax * (P.N + 1);
     const int stride = P.nwaves * 64 / kTileDev;
-    const int needc = (ncell + stride - 1) / stride;
+    // cells per thread; the two-axis stage keeps the two cells of a step together
+    const int needc = P.mixed ? 2 * ((P.N + 1 + stride - 1) / stride) : (ncell + stride - 1) / stride;
     int needi = 0;
     for (int w = 0; w < P.nwaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
     if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }

@@ -236,11 +236,11 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
     const bool six = mdl.family == TG_FAM_6DOF, xy = mdl.family == TG_FAM_XY;
     const int D = six ? 2 : 3, S = D + 1, nax = six ? 3 : (xy ? 2 : 1);
     sp.D = D; sp.nax = nax;
-    sp.nblk = six ? 3 : 1;
+    sp.nblk = nax;
     const int per_axis = S * (N + 1);
-    sp.nb = six ? per_axis : nax * per_axis;   // rows of one block, also the stride between blocks
+    sp.nb = per_axis;                           // rows of one block, also the stride between blocks
     sp.n_int = sp.nblk * sp.nb;
-    for (int a = 0; a < nax; a++) sp.axis_base[a] = six ? a * sp.nb : a * per_axis;
+    for (int a = 0; a < nax; a++) sp.axis_base[a] = a * sp.nb;
     sp.var_ref.assign(sp.n_int, -1);
     std::vector<int> blk_of(n, -1);
     for (int a = 0; a < nax; a++)
@@ -255,8 +255,9 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
                 blk_of[ref] = ji / sp.nb;
             }
     for (int j = 0; j < n; j++) if (blk_of[j] < 0) { err = "internal: variable not mapped"; return false; }
-    // the blocks must be decoupled in K (6-DOF: the three axes never interact)
-    for (int i = 0; i < n; i++)
+    // the blocks must be decoupled in K (6-DOF: the three axes never interact); the XY stage's
+    // mixed rows couple its two axes, see below
+    for (int i = 0; i < n && !xy; i++)
         for (int j = 0; j < n; j++)
             if (blk_of[i] != blk_of[j] && K[(size_t)i * n + j] != 0.0) { err = "internal: axes are coupled"; return false; }
     // operators: blocks whose K sub-matrices coincide share one inverse
@@ -278,16 +279,39 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
         if (sp.op_of_block[b] < 0) { sp.op_of_block[b] = (int)op_rep.size(); op_rep.push_back(b); }
     }
     sp.nops = (int)op_rep.size();
+    // XY: x and y are interchangeable in K (same weights and step sizes, and a swap of the axes
+    // maps the set of mixed rows onto itself), so K^-1 = [[E, F], [F, E]] and the kernel applies
+    // (E + F) / 2 to the sum and (E - F) / 2 to the difference of the two axes' right-hand sides:
+    // two products of half the size instead of one.
+    if (xy) {
+        double worst = 0.0, scale = 0.0;
+        for (int i = 0; i < sp.nb; i++)
+            for (int j = 0; j < sp.nb; j++) {
+                int xi = vref(0, i), xj = vref(0, j), yi = vref(1, i), yj = vref(1, j);
+                if ((xi < 0) != (yi < 0) || (xj < 0) != (yj < 0)) { err = "internal: XY axes are laid out differently"; return false; }
+                if (xi < 0 || xj < 0) continue;
+                double e = sp.Kinv[(size_t)xi * n + xj], f = sp.Kinv[(size_t)xi * n + yj];
+                worst = std::max(worst, std::fabs(e - sp.Kinv[(size_t)yi * n + yj]));
+                worst = std::max(worst, std::fabs(f - sp.Kinv[(size_t)yi * n + xj]));
+                scale = std::max(scale, std::fabs(e));
+            }
+        if (!(worst <= 1e-9 * scale)) { err = "internal: the XY operator is not symmetric in its two axes"; return false; }
+        sp.nops = 2; sp.op_of_block[0] = 0; sp.op_of_block[1] = 1;
+    }
     // operator fragments: Mfrag[op][rb][kk][lane] = Kinv_block[rb*16 + (lane&15)][4*kk + (lane>>4)]
     const int nrb = (sp.nb + 15) / 16, ks = (sp.nb + 3) / 4, ksa = ks + kRingDepth;   // zero steps: prefetch overrun
     sp.Mfrag.assign((size_t)sp.nops * nrb * ksa * 64, 0.0);
     for (int o = 0; o < sp.nops; o++) {
-        const int b = op_rep[o];
+        const int b = xy ? 0 : op_rep[o];
         for (int rb = 0; rb < nrb; rb++)
             for (int kk = 0; kk < ks; kk++)
                 for (int lane = 0; lane < 64; lane++) {
                     int ri = vref(b, rb * 16 + (lane & 15)), rk = vref(b, 4 * kk + (lane >> 4));
                     double v = (ri >= 0 && rk >= 0) ? sp.Kinv[(size_t)ri * n + rk] : 0.0;
+                    if (xy && ri >= 0 && rk >= 0) {
+                        const double f = sp.Kinv[(size_t)ri * n + vref(1, 4 * kk + (lane >> 4))];
+                        v = 0.5 * (o == 0 ? v + f : v - f);
+                    }
                     sp.Mfrag[(((size_t)o * nrb + rb) * ksa + kk) * 64 + lane] = v;
                 }
     }
