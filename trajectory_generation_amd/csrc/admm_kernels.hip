@@ -181,6 +181,20 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         }
     }
 
+    // Step sizes and box bounds of the thread's cells, in registers when few cells per thread leave
+    // room: the LDS pipe is the busiest unit of the rhs and projection phases.  Slots 1.. have
+    // symmetric bounds in every stage (the host checks); slot 0 keeps both ends (altitude floor).
+    constexpr bool REGC = MAXC <= 2 && !MIXED;
+    double c_rho[REGC ? MAXC : 1][S], c_hi[REGC ? MAXC : 1][S], c_lo0[REGC ? MAXC : 1];
+    if constexpr (REGC) {
+#pragma unroll
+        for (int cc = 0; cc < MAXC; cc++) {
+#pragma unroll
+            for (int k = 0; k < S; k++) { c_rho[cc][k] = lds[i_ct[cc] + k * 3]; c_hi[cc][k] = lds[i_ct[cc] + k * 3 + 2]; }
+            c_lo0[cc] = lds[i_ct[cc] + 1];
+        }
+    }
+
     // Start the slot's instance `inst` (fresh slots only; the others keep their state): iterates
     // zero or the previous solve's, q, the step-0 bound, the per-instance boxes, and the w of the
     // first rhs.  Returns the slot's part of ||q||_inf.
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
                 if constexpr (G > 1) {
 #pragma unroll
-                    for (int k = 0; k < S; k++) rr[j][k] = lds[i_ct[cc] + k * 3];
+                    for (int k = 0; k < S; k++) rr[j][k] = REGC ? c_rho[cc][k] : lds[i_ct[cc] + k * 3];
                 }
                 mixc[j][0] = mixc[j][1] = mixc[j][2] = 0.0;
                 if (MIXED) {
@@ -434,16 +448,24 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                                 if constexpr (TWO) bf1[kk] = bp1[kk * 64];
                             }
                             __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA chain
+                            // A dependent MFMA issues every 128 clocks, an independent one every 64:
+                            // a single product is split over two accumulators (even / odd k steps),
+                            // in case the wave has its SIMD to itself during this phase.
                             d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
 #pragma unroll
                             for (int kk = 0; kk < KSREG; kk++) {
 #if !(TG_ABLATE & 1)
-                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c0, 0, 0, 0);
+                                if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c0, 0, 0, 0);
+                                else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c1, 0, 0, 0);
                                 if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf1[kk], c1, 0, 0, 0);
 #else
                                 c0[0] += mreg[kk] * bf0[kk];
                                 if constexpr (TWO) c1[0] += mreg[kk] * bf1[kk];
 #endif
+                            }
+                            if constexpr (!TWO) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) c0[r] += c1[r];
                             }
                             if constexpr (SEP) store(grp, rb, TWO, c0, c1);
                             else { acc0[0] = c0; if constexpr (PAIR) acc1[0] = c1; }
@@ -526,8 +548,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         xt[j][k] = xin[k * 16]; xp[j][k] = xpr[k * 16];
                         if constexpr (G > 1) {
                             if (MIXED && (k == 1 || k == 2)) { bnd[j][k][1] = hiv[cc][k - 1]; bnd[j][k][0] = -bnd[j][k][1]; }
+                            else if (REGC) { bnd[j][k][1] = c_hi[cc][k]; bnd[j][k][0] = k == 0 ? c_lo0[cc] : -c_hi[cc][k]; }
                             else { bnd[j][k][0] = ct[k * 3 + 1]; bnd[j][k][1] = ct[k * 3 + 2]; }
-                            if constexpr (CHK) rr[j][k] = ct[k * 3];
+                            if constexpr (CHK) rr[j][k] = REGC ? c_rho[cc][k] : ct[k * 3];
                         }
                     }
                     if constexpr (G > 1) {
@@ -1129,21 +1152,30 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     const int S = P.D + 1;
     const int rows_init = (P.separate_xt ? 2 : 1) * (P.n_int + S) + ncell * P.D + P.D +
                           (P.mixed ? (P.N + 1) * 6 + 6 : 0) + 8 + P.nax * P.D;
+    // the variants with few cells per thread keep the box bounds in registers as (hi, -hi) for
+    // every slot but the first
+    bool sym = true;
+    for (int a = 0; a < P.nax; a++)
+        for (int k = 1; k <= P.D; k++) sym = sym && P.lb[a][k] == -P.ub[a][k];
     auto fits = [&](int ksreg) { return P.ks <= ksreg && (P.n_int - P.nb) + 4 * ksreg <= rows_init; };
     if (P.nwaves != 8) { *why = "only 8-wave workgroups are compiled"; return hipErrorInvalidValue; }
     const bool sep = P.separate_xt != 0;
+    // the most general variant of each family keeps rhs and xt in one LDS vector; it also takes what
+    // the faster variants decline
+    StageDev single = P;
+    single.separate_xt = 0;
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(P, a, s);
+        if (sym && sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(P, a, s);
         if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(P, a, s);
-        if (!sep && needc <= 8 && needi <= 4) return launch_admm_t<512, 2, 3, false, 8, 4, true, 0, false>(P, a, s);
+        if (needc <= 8 && needi <= 4) return launch_admm_t<512, 2, 3, false, 8, 4, true, 0, false>(single, a, s);
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
         if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(P, a, s);
         if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(P, a, s);
-        if (!sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false>(P, a, s);
+        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false>(single, a, s);
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (sep && needc <= 1 && needi <= 1 && fits(24)) return launch_admm_t<512, 3, 1, false, 1, 1, false, 24, true>(P, a, s);
-        if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(P, a, s);
-        if (!sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 1, false, 4, 4, false, 0, false>(P, a, s);
+        if (sym && sep && needc <= 1 && needi <= 1 && fits(21)) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(P, a, s);
+        if (sym && sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(P, a, s);
+        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 1, false, 4, 4, false, 0, false>(single, a, s);
     }
     *why = "horizon too long for the compiled kernel variants";
     return hipErrorInvalidValue;
