@@ -186,6 +186,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // symmetric bounds in every stage (the host checks); slot 0 keeps both ends (altitude floor).
     constexpr bool REGC = MAXC <= 2 && !MIXED;
     double c_rho[REGC ? MAXC : 1][S], c_hi[REGC ? MAXC : 1][S], c_lo0[REGC ? MAXC : 1];
+    double c_bg[REGC ? MAXC : 1][D];   // the cell's dynamics-row bound (-x0 at step 0, else zero), set by load()
     if constexpr (REGC) {
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 // the first projection relaxes with the starting z (zero, or the previous solve's):
                 // alpha zt + (1-alpha) z0 + y = alpha zt + (1-alpha) b + [y + (1-alpha)(z0 - b)]
                 yg[cc][k] += oma * (zg0[k] - b0[k]);
+                if constexpr (REGC) c_bg[cc][k] = b0[k];
             }
         }
         if (MIXED) {
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                     if constexpr (G > 1) {
 #pragma unroll
-                        for (int k = 0; k < D; k++) bg[j][k] = lds[i_bg[cc] + k * 16];
+                        for (int k = 0; k < D; k++) bg[j][k] = REGC ? c_bg[cc][k] : lds[i_bg[cc] + k * 16];
                     }
                 }
                 if constexpr (MIXED) {
