@@ -417,6 +417,24 @@ def test_slot_refill_is_bit_identical_6dof(tg, oracle, fine, cap):
     assert np.abs(res[1][0]["X"][idx] - ro["X"]).max() < 1e-9
 
 
+def test_slot_refill_needs_aligned_checks(tg, oracle):
+    """max_iter that is no multiple of the check interval (or a check_fine that does not divide
+    it): the solve falls back to one workgroup per tile instead of refilling slots, with the same
+    results, and an instance that runs out of iterations stops exactly at max_iter."""
+    N, B = 10, 70
+    p, op = _p6_pair(tg, oracle, N=N)
+    x0, ref = oracle.synth_mpc6(5, N, 0.1, B)
+    x0[33, 3] = 50.0
+    for kw in (dict(max_iter=130, eps_prim_inf=0.0), dict(max_iter=150, check_fine=10, eps_prim_inf=0.0)):
+        a = tg.BatchedMPC6(p, tg.make_opts(grid_cap=-1, **kw)).solve_host(x0, ref)
+        b = tg.BatchedMPC6(p, tg.make_opts(grid_cap=1, **kw)).solve_host(x0, ref)
+        np.testing.assert_array_equal(a["status"], b["status"])
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+        assert a["status"][33] == -2 and a["iters"][33] == kw["max_iter"]
+        ok = a["status"] == 1
+        assert ok.sum() == B - 1 and np.abs(a["X"][ok] - b["X"][ok]).max() == 0.0
+
+
 def test_slot_refill_is_bit_identical_12state(tg, oracle):
     """The same for the three chained stages, with an instance whose XY stage is infeasible: its
     yaw stage is skipped when the slot reaches it through the queue, too."""
