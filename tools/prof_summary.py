@@ -56,6 +56,39 @@ def main(src, dst_prefix, workload):
         out["hbm_bytes_per_launch_fetch_x2"] = 2 * raw + wr
         lines.append("HBM bytes per launch: raw %.0f, with the gfx950 FETCH_SIZE x2 correction %.0f" %
                      (raw + wr, 2 * raw + wr))
+    db = one_db(os.path.join(src, "pmc_sq"))
+    if db:
+        # SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves,
+        # SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs (64 per v_mfma_f64_16x16x4_f64),
+        # SQ_LDS_IDX_ACTIVE LDS-array cycles summed over CUs, GRBM_GUI_ACTIVE cycles summed over 8 XCDs
+        lines.append("")
+        lines.append("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS "
+                     "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE (means per launch)")
+        sq = {}
+        for k, c, v, n in db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+                                     "where kernel_name like '%admm_kernel%' group by kernel_name, counter_name"):
+            sq.setdefault(k, {})[c] = v
+            sq[k]["launches"] = n
+        out["sq"] = {}
+        for k, d in sq.items():
+            wc = d["SQ_WAVE_CYCLES"]
+            gui = d["GRBM_GUI_ACTIVE"] / 8.0                      # kernel duration in shader cycles
+            o = {"launches": d["launches"],
+                 "wave_parked_frac": d["SQ_WAIT_ANY"] / wc, "wave_issue_stall_frac": d["SQ_WAIT_INST_ANY"] / wc,
+                 "wave_issuing_frac": d["SQ_ACTIVE_INST_ANY"] / wc, "wave_lds_issue_stall_frac": d["SQ_WAIT_INST_LDS"] / wc,
+                 "mfma_pipe_busy_frac": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui),
+                 "lds_array_busy_frac": d["SQ_LDS_IDX_ACTIVE"] / (256.0 * gui),
+                 "lds_bank_conflict_frac_of_lds_cycles": d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0),
+                 "mfma_instructions": d["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0, "kernel_cycles": gui}
+            out["sq"][k] = o
+            lines.append(k[:100])
+            lines.append("  launches %d, %.0f shader cycles per launch" % (o["launches"], gui))
+            lines.append("  wave time: parked at s_waitcnt / barrier %.1f %%, stalled at issue %.1f %% (of which LDS %.1f %%), issuing %.1f %%"
+                         % (100 * o["wave_parked_frac"], 100 * o["wave_issue_stall_frac"], 100 * o["wave_lds_issue_stall_frac"],
+                            100 * o["wave_issuing_frac"]))
+            lines.append("  MFMA pipe busy %.1f %% of SIMD cycles (%.0f MFMAs), LDS array busy %.1f %% of CU cycles, bank conflicts %.2f %% of LDS cycles"
+                         % (100 * o["mfma_pipe_busy_frac"], o["mfma_instructions"], 100 * o["lds_array_busy_frac"],
+                            100 * o["lds_bank_conflict_frac_of_lds_cycles"]))
     os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)
     if "hbm_bytes_per_launch_fetch_x2" in out:
         # per-workload HBM bytes per launch of the dominant kernel, read by bench.py ("traffic")
