@@ -173,6 +173,46 @@ def test_solve_matches_oracle_12state(tg, oracle, N, B):
     assert np.abs(r["X"] - ro["X"]).max() < 1e-8 and np.abs(r["U"] - ro["U"]).max() < 1e-8
 
 
+@pytest.mark.parametrize("N,B,smooth,stress", [(20, 24, True, False), (20, 24, False, True), (20, 16, True, True),
+                                               (32, 6, False, False), (40, 5, False, True), (10, 40, True, False)])
+def test_solve_matches_oracle_12state_variants(tg, oracle, N, B, smooth, stress):
+    """Input smoothing (the test main's setting, mpc_12state.cpp:314-435), the test main's geometry
+    on every instance (limits active along most of the horizon), and horizons between the compiled
+    kernel variants: statuses, iteration counts and solutions as the oracle's."""
+    from trajectory_generation_amd import synth
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N, enable_control_smoothing=smooth))
+    op = oracle.mpc12_params(N=N, enable_control_smoothing=smooth)
+    x12, ref12 = oracle.synth_mpc12(SEED + 7, N, 0.1, B)
+    if stress:
+        x12, ref12 = synth.stress("12state", x12, ref12, N)
+    r = eng.solve_host(x12, ref12)
+    s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
+    oracle.match_rho_classes(eng.rho_rows())
+    ro = oracle.mpc12_batch(op, s, x12, ref12)
+    np.testing.assert_array_equal(r["status"], ro["status"])
+    np.testing.assert_array_equal(r["iters"], ro["iters"])
+    ok = (r["status"] == 1).all(1)
+    assert ok.mean() >= 0.5
+    assert np.abs(r["X"][ok] - ro["X"][ok]).max() < 1e-8 and np.abs(r["U"][ok] - ro["U"][ok]).max() < 1e-8
+
+
+@pytest.mark.parametrize("N,B", [(20, 40), (50, 8), (30, 12)])
+def test_solve_matches_oracle_6dof_stress(tg, oracle, N, B):
+    """Target 40 m above every vehicle: velocity and input limits active, many more iterations."""
+    from trajectory_generation_amd import synth
+    p, op = _p6_pair(tg, oracle, N=N)
+    eng = tg.BatchedMPC6(p)
+    x0, ref = oracle.synth_mpc6(SEED + 8, N, 0.1, B)
+    x0, ref = synth.stress("6dof", x0, ref, N)
+    r = eng.solve_host(x0, ref)
+    oracle.match_rho_classes(eng.rho_rows())
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
+    np.testing.assert_array_equal(r["status"], ro["status"])
+    np.testing.assert_array_equal(r["iters"], ro["iters"])
+    assert (r["status"] == 1).all() and r["iters"].max() > 25
+    assert np.abs(r["X"] - ro["X"]).max() < 1e-9 and np.abs(r["U"] - ro["U"]).max() < 1e-9
+
+
 def test_12state_stage_by_stage_with_injected_upstream(tg, oracle, golden_dir):
     """Each stage solved on the GPU with the certified upstream solution injected (the XY bounds
     are a discontinuous function of the Z solution, so stages are compared one at a time)."""

@@ -100,6 +100,23 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         return c < ncell ? c : ncell;
     };
 
+    // register-resident operator fragments: requested first, so that their L2 latency passes
+    // behind the set-up below
+    const int nit = P.wi_cnt[wave];
+    double mreg[KSREG > 0 ? KSREG : 1];
+    // the single MFMA item of a wave whose fragments are register resident, looked up once
+    const int grp_r = P.wi_grp[wave][0], rb_r = P.wi_rb[wave][0];
+    const bool two_r = PAIR && P.grp_cnt[grp_r] == 2;
+    const int boff_r = (P.grp_first[grp_r] * nb + (lane >> 4)) * 16 + (lane & 15);
+    if constexpr (KSREG > 0) {
+        const int grp = grp_r, rb = rb_r;
+#pragma unroll
+        for (int kk = 0; kk < KSREG; kk++) {
+            const bool in = nit > 0 && kk < ks;
+            mreg[kk] = in ? P.Mfrag[(((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc + kk) * 64 + lane] : 0.0;
+        }
+    }
+
     const int V0 = 0;
     const int VX = SEP ? (n_int + S) * 16 : 0;
     const int WEQ = (SEP ? 2 : 1) * (n_int + S) * 16;
@@ -306,21 +323,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         __syncthreads();
         qf = wave_gmax(qf);
         if ((lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
-    }
-
-    const int nit = P.wi_cnt[wave];
-    double mreg[KSREG > 0 ? KSREG : 1];
-    // the single MFMA item of a wave whose fragments are register resident, looked up once
-    const int grp_r = P.wi_grp[wave][0], rb_r = P.wi_rb[wave][0];
-    const bool two_r = PAIR && P.grp_cnt[grp_r] == 2;
-    const int boff_r = (P.grp_first[grp_r] * nb + (lane >> 4)) * 16 + (lane & 15);
-    if constexpr (KSREG > 0) {
-        const int grp = grp_r, rb = rb_r;
-#pragma unroll
-        for (int kk = 0; kk < KSREG; kk++) {
-            const bool in = nit > 0 && kk < ks;
-            mreg[kk] = in ? P.Mfrag[(((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc + kk) * 64 + lane] : 0.0;
-        }
     }
 
     const int max_iter = P.max_iter, check = P.check, fine = P.check_fine;
