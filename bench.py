@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--max-iter", type=int, default=4000, help="ADMM iteration budget per solve (OSQP default 4000)")
     ap.add_argument("--check", type=int, default=25, help="termination check interval (OSQP default 25)")
     ap.add_argument("--grid-cap", type=int, default=0, help="most workgroups per solve (0: what the GPU holds at once, -1: one per tile of 16 instances)")
+    ap.add_argument("--lowrank", type=int, default=0, help="K^-1 as diagonal tiles + low-rank rest: 0 where it pays, 1 wherever possible, -1 dense")
     ap.add_argument("--check-fine", type=int, default=None, help="check interval after the first check (0: OSQP's fixed interval)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
@@ -138,7 +139,7 @@ def main():
         # the yaw reference), and iterates nearer the tolerance make more of those infeasible or
         # slow to certify as such.
         args.check_fine = 5 if args.workload == "mpc_6dof_B4096_N20" else 0
-    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check, check_fine=args.check_fine, grid_cap=args.grid_cap)
+    opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check, check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank)
     first = rank * B                       # weak scaling: every rank owns its own slab of B instances
     if model == "6dof":
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
@@ -249,7 +250,7 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "model": None, "instances_per_gpu": B, "horizon_N": N,
-                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "grid_cap": args.grid_cap,
+                   "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check, "check_fine": args.check_fine, "grid_cap": args.grid_cap, "lowrank": args.lowrank,
                    "smoothing": bool(args.smoothing), "inputs": "stress" if args.stress else "seeded", "rho": eng.rho if model == "6dof" else
                    [eng.rho(k) for k in ("xy", "z", "yaw")], "parallelism": "instances sharded x%d" % world},
         "p50_batch_ms": float(np.median(lat)),

@@ -97,6 +97,13 @@ typedef struct {
      * check_termination and check_termination a multiple of check_fine (at most 32 times it);
      * otherwise, or with a negative value, every tile gets a workgroup of its own. */
     int    grid_cap;
+    /* How K^-1 is applied.  K is block tridiagonal, so outside its 16 x 16 diagonal tiles a tile
+     * row of K^-1 has rank <= 2 x (integrator order [+ 1 with input smoothing]); the engine can
+     * apply it as diagonal tile + low-rank rest, with less than half the matrix-core work of the
+     * dense product on long horizons.  0: where it pays (horizons too long for register-resident
+     * operators), 1: wherever the computed inverse has the structure to working precision,
+     * -1: dense always.  The two forms agree to rounding (1e-15 relative). */
+    int    lowrank;
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

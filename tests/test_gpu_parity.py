@@ -213,6 +213,39 @@ def test_solve_matches_oracle_6dof_stress(tg, oracle, N, B):
     assert np.abs(r["X"] - ro["X"]).max() < 1e-9 and np.abs(r["U"] - ro["U"]).max() < 1e-9
 
 
+@pytest.mark.parametrize("model,N,B,smooth", [("6dof", 5, 9, False), ("6dof", 20, 40, False), ("6dof", 20, 20, True),
+                                              ("6dof", 50, 20, False), ("6dof", 33, 10, True), ("12state", 20, 24, False),
+                                              ("12state", 50, 5, False), ("12state", 12, 7, True)])
+def test_lowrank_operator_form_matches_oracle(tg, oracle, model, N, B, smooth):
+    """K^-1 applied as diagonal tiles + low-rank rest (forced on, also where the dense form would
+    be chosen): the same statuses, iteration counts and solutions as the oracle, which factorises
+    the KKT matrix; the dense form on the same inputs agrees to 1e-9 as well."""
+    if model == "6dof":
+        p, op = _p6_pair(tg, oracle, N=N, enable_control_smoothing=smooth)
+        x0, ref = oracle.synth_mpc6(SEED + 9, N, 0.1, B)
+        lr = tg.BatchedMPC6(p, tg.make_opts(lowrank=1)); de = tg.BatchedMPC6(p, tg.make_opts(lowrank=-1))
+        r, rd = lr.solve_host(x0, ref), de.solve_host(x0, ref)
+        oracle.match_rho_classes(lr.rho_rows())
+        ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(lr.rho, warm_start=0), x0, ref)
+        ok = r["status"] == 1
+    else:
+        x0, ref = oracle.synth_mpc12(SEED + 9, N, 0.1, B)
+        kw = dict(N=N, enable_control_smoothing=smooth)
+        lr = tg.BatchedMPC12(tg.mpc12_params(**kw), tg.make_opts(lowrank=1))
+        de = tg.BatchedMPC12(tg.mpc12_params(**kw), tg.make_opts(lowrank=-1))
+        r, rd = lr.solve_host(x0, ref), de.solve_host(x0, ref)
+        s = {k: oracle.fixed_rho_settings(lr.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
+        oracle.match_rho_classes(lr.rho_rows())
+        ro = oracle.mpc12_batch(oracle.mpc12_params(**kw), s, x0, ref)
+        ok = (r["status"] == 1).all(1)
+    np.testing.assert_array_equal(r["status"], ro["status"])
+    np.testing.assert_array_equal(r["iters"], ro["iters"])
+    np.testing.assert_array_equal(r["iters"], rd["iters"])
+    assert ok.mean() >= 0.5
+    assert np.abs(r["X"][ok] - ro["X"][ok]).max() < 1e-8 and np.abs(r["U"][ok] - ro["U"][ok]).max() < 1e-8
+    assert np.abs(r["X"][ok] - rd["X"][ok]).max() < 1e-8
+
+
 def test_12state_stage_by_stage_with_injected_upstream(tg, oracle, golden_dir):
     """Each stage solved on the GPU with the certified upstream solution injected (the XY bounds
     are a discontinuous function of the Z solution, so stages are compared one at a time)."""

@@ -6,8 +6,8 @@ import numpy as np, torch
 import trajectory_generation_amd as tg
 from trajectory_generation_amd import synth
 
-def run(model, N, B, iters=200, reps=5, check=25):
-    opts = tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=check, eps_prim_inf=0.0, check_fine=0)
+def run(model, N, B, iters=200, reps=5, check=25, lowrank=0):
+    opts = tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=check, eps_prim_inf=0.0, check_fine=0, lowrank=lowrank)
     if model == "6dof":
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts); x0, ref = synth.mpc6(1, N, 0.1, B)
         flops = 3 * 2 * (3 * N + 2) ** 2
@@ -23,13 +23,13 @@ def run(model, N, B, iters=200, reps=5, check=25):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
     wgs = (B + 15) // 16
     waves = max(1.0, wgs / 256.0)
-    print(f"{model} N={N} B={B} check={check}: {dt*1e3:.3f} ms / {iters} iters = {dt/iters*1e6:.2f} us/iter/launch; "
+    print(f"{model} N={N} B={B} check={check} lowrank={lowrank}: {dt*1e3:.3f} ms / {iters} iters = {dt/iters*1e6:.2f} us/iter/launch; "
           f"per-WG-iteration {dt/iters*1e6/waves:.2f} us (WGs/CU {waves:.1f}); {B*iters*flops/dt/1e12:.2f} TFLOP/s", flush=True)
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         run(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 200,
-            check=int(sys.argv[5]) if len(sys.argv) > 5 else 25)
+            check=int(sys.argv[5]) if len(sys.argv) > 5 else 25, lowrank=int(sys.argv[6]) if len(sys.argv) > 6 else 0)
     else:
         for B in (4096, 8192, 16384, 65536):
             run("6dof", 20, B)

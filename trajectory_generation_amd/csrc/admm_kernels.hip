@@ -71,7 +71,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
 //   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
-template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP>
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int VX = SEP ? (n_int + S) * 16 : 0;
     const int WEQ = (SEP ? 2 : 1) * (n_int + S) * 16;
     const int WMX = WEQ + (ncell * D + D) * 16;
-    const int ZERO = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);
+    const int SB = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);                   // LR: C r of every block, [blocks][sb_rows][16]
+    const int ZERO = SB + (LR ? (n_int / nb) * P.sb_rows * 16 : 0);
     const int BGT = ZERO + 8 * 16;                                           // [NAX][D][16] -x0: l = u of the step-0 rows
     const int CTAB = BGT + NAX * D * 16;                                     // [NAX][S][3] rho, lb, ub
     unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
@@ -417,6 +418,110 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
         // D[16 rows x 16 instances] += A[16 x 4] * B[4 x 16]: A = operator fragment (registers
         // when it fits, else streamed from L2 through a prefetch ring), B = rhs rows from LDS
+        if constexpr (LR) {
+            // Block-row low-rank form: stage 1, s = C r for every block (the stacked C streams from
+            // L2 like a dense operator with few rows); stage 2, per 16-row tile I,
+            // xt_I = D_I r_I + U_I s_I written over r_I: only the tile's own wave reads or writes
+            // those rows after the barrier, so rhs and xt share one vector without another barrier.
+            constexpr int PD = kRingDepth;
+            const int q = P.lr_q, crb = P.lr_crb, uk = P.lr_uk, srows = nrb * q;
+#pragma unroll
+            for (int it = 0; it < MAXIT; it++) {
+                if (it < nit) {
+                    const int grp = P.wi_grp[wave][it], rb = P.wi_rb[wave][it];
+                    const bool two = PAIR && P.grp_cnt[grp] == 2;
+                    const double *bp0 = v0 + (P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15);
+                    const double *bp1 = bp0 + (size_t)nb * 16;
+                    const double *Mrow = P.Mfrag + ((size_t)P.grp_op[grp] * crb + rb) * P.ks_alloc * 64 + lane;
+                    auto run = [&](auto two_c) __attribute__((always_inline)) {
+                        constexpr bool TWO = decltype(two_c)::value;
+                        double af[PD];
+#pragma unroll
+                        for (int p = 0; p < PD; p++) af[p] = Mrow[p * 64];
+                        d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+                        const int full = ks / PD, rem = ks - full * PD;
+                        const double *mp = Mrow + PD * 64, *b0 = bp0, *b1 = bp1;
+                        for (int f = 0; f < full; f++) {
+#pragma unroll
+                            for (int p = 0; p < PD; p++) {
+                                const double bf0 = b0[p * 64];
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                if constexpr (TWO) {
+                                    const double bf1 = b1[p * 64];
+                                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
+                                }
+                                af[p] = mp[p * 64];
+                            }
+                            mp += PD * 64; b0 += PD * 64; b1 += PD * 64;
+                        }
+#pragma unroll
+                        for (int p = 0; p < PD; p++) {
+                            if (p < rem) {
+                                const double bf0 = b0[p * 64];
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                if constexpr (TWO) {
+                                    const double bf1 = b1[p * 64];
+                                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
+                                }
+                            }
+                        }
+                        double *o0 = lds + SB + ((size_t)P.grp_first[grp] * P.sb_rows + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
+                        const int row0 = rb * 16 + (lane >> 4);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < srows) o0[r * 64] = c0[r];
+                        if constexpr (TWO) {
+                            double *o1 = o0 + (size_t)P.sb_rows * 16;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (row0 + 4 * r < srows) o1[r * 64] = c1[r];
+                        }
+                    };
+                    if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
+                }
+            }
+            __syncthreads();
+            const int njt = P.wj_cnt[wave];
+#pragma unroll
+            for (int jt = 0; jt < MAXIT; jt++) {
+                if (jt < njt) {
+                    const int grp = P.wj_grp[wave][jt], I = P.wj_rb[wave][jt];
+                    const bool two = PAIR && P.grp_cnt[grp] == 2;
+                    const int blk = P.grp_first[grp];
+                    const double *fr = P.DUfrag + ((size_t)P.grp_op[grp] * nrb + I) * (4 + uk) * 64 + lane;
+                    double *r0p = v0 + ((size_t)blk * nb + I * 16 + (lane >> 4)) * 16 + (lane & 15);
+                    const double *s0p = lds + SB + ((size_t)blk * P.sb_rows + I * q + (lane >> 4)) * 16 + (lane & 15);
+                    auto run = [&](auto two_c) __attribute__((always_inline)) {
+                        constexpr bool TWO = decltype(two_c)::value;
+                        constexpr int KD = 6;                      // 4 k-steps of D_I + at most 2 of U_I
+                        double af[KD], bf0[KD], bf1[TWO ? KD : 1];
+#pragma unroll
+                        for (int kk = 0; kk < KD; kk++) {
+                            const bool in = kk < 4 + uk;
+                            af[kk] = in ? fr[kk * 64] : 0.0;
+                            const double *b = kk < 4 ? r0p + kk * 64 : s0p + (kk - 4) * 64;
+                            bf0[kk] = in ? b[0] : 0.0;
+                            if constexpr (TWO) bf1[kk] = in ? b[(size_t)(kk < 4 ? nb : P.sb_rows) * 16] : 0.0;
+                        }
+                        d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+#pragma unroll
+                        for (int kk = 0; kk < KD; kk++) {
+                            if (kk < 4 + uk) {
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf0[kk], c0, 0, 0, 0);
+                                if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf1[kk], c1, 0, 0, 0);
+                            }
+                        }
+                        const int row0 = I * 16 + (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) r0p[r * 64] = c0[r];
+                        if constexpr (TWO) {
+                            double *r1p = r0p + (size_t)nb * 16;
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) r1p[r * 64] = c1[r];
+                        }
+                    };
+                    if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
+                }
+            }
+        } else
         {
             // with a separate xt vector (SEP) an item's rows are stored as soon as they are done;
             // otherwise xt overwrites the rhs and the stores wait for every wave's last read
@@ -1085,14 +1190,15 @@ size_t admm_lds_bytes(const StageDev &P)
 {
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
-                  (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D;
+                  (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D +
+                  (P.lr ? (size_t)(P.n_int / P.nb) * P.sb_rows : 0);
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves + 1) * 16 * sizeof(double);
 }
 
-template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP>
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR>;
     const size_t lds_bytes = admm_lds_bytes(P);
     // the dynamic LDS limit of a kernel is per device and sticky: raise it when it has to grow
     static int lds_set[64] = {0};
@@ -1168,6 +1274,23 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     // the faster variants decline
     StageDev single = P;
     single.separate_xt = 0;
+    int needj = 0;
+    for (int w = 0; w < P.nwaves; w++) needj = P.wj_cnt[w] > needj ? P.wj_cnt[w] : needj;
+    if (P.lr) {
+        // block-row low-rank operators: rhs and xt share one vector
+        if (sep) { *why = "internal: the low-rank form keeps rhs and xt in one vector"; return hipErrorInvalidValue; }
+        const int items = needi > needj ? needi : needj;
+        if (P.D == 2 && P.nax == 3 && !P.mixed && needc <= 5 && items <= 3)
+            return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(P, a, s);
+        if (P.D == 3 && P.nax == 2 && P.mixed && needc <= 2 && items <= 2)
+            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, false, true>(P, a, s);
+        if (P.D == 3 && P.nax == 2 && P.mixed && needc <= 4 && items <= 4)
+            return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false, true>(P, a, s);
+        if (P.D == 3 && P.nax == 1 && !P.mixed && needc <= 2 && items <= 2)
+            return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, false, true>(P, a, s);
+        *why = "horizon too long for the compiled kernel variants";
+        return hipErrorInvalidValue;
+    }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
         if (sym && sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(P, a, s);
         if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(P, a, s);

@@ -31,6 +31,14 @@ struct StageDev {
     int wi_cnt[kAdmmWaves];
     unsigned char wi_grp[kAdmmWaves][kMaxItems], wi_rb[kAdmmWaves][kMaxItems];
     const double *Mfrag;         // [nops][nrb][ks_alloc][64] operator fragments, MFMA A-operand order
+    // Block-row low-rank form (lr != 0): x_I = D_I r_I + U_I (C_I r) per 16-row tile I.  Mfrag then
+    // holds the stacked C ([nops][lr_crb][ks_alloc][64]; wi_* items are (group, row block of C)),
+    // DUfrag the tiles' D_I and U_I ([nops][nrb][4 + lr_uk][64]; wj_* items are (group, tile)).
+    int lr, lr_q, lr_crb, lr_uk;
+    int sb_rows;                 // LDS rows per block for C r: lr_crb * 16 + 8
+    const double *DUfrag;
+    int wj_cnt[kAdmmWaves];
+    unsigned char wj_grp[kAdmmWaves][kMaxItems], wj_rb[kAdmmWaves][kMaxItems];
     double dt, c2;               // c2 = dt^2/2 (position <- acceleration coupling, D = 3)
     double qw[kMaxAxes];         // q(position slot) = qw * ref            (qw = -state weight)
     double pdiag[kMaxAxes];      // P diagonal on the position slot

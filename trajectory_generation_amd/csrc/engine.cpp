@@ -70,7 +70,8 @@ struct DevStage {
     StageProblem sp;
     StageDev dev{};
     AsmDev adev{};
-    double *d_Mfrag = nullptr;
+    double *d_Mfrag = nullptr, *d_DUfrag = nullptr;
+    int lowrank_mode = 0;     // 0: when it pays, 1: whenever the operators allow it, -1: never
     int *d_queue = nullptr;   // ticket counter of the kernel's instance queue
     int grid_cap = 0;
     double *d_qw = nullptr, *d_lt = nullptr, *d_ut = nullptr;
@@ -86,6 +87,7 @@ struct DevStage {
         if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
         HIP_TRY(hipMalloc((void **)&d_queue, sizeof(int)));
         grid_cap = o.grid_cap;
+        lowrank_mode = o.lowrank;
         if ((rc = upload(sp.q_w, &d_qw))) return rc;
         if ((rc = upload(sp.l_t, &d_lt))) return rc;
         if ((rc = upload(sp.u_t, &d_ut))) return rc;
@@ -104,28 +106,52 @@ struct DevStage {
             dev.grp_first[dev.ngrp] = b; dev.grp_cnt[dev.ngrp] = cnt; dev.grp_op[dev.ngrp] = sp.op_of_block[b];
             dev.ngrp++; b += cnt;
         }
-        // deal the (group, row block) MFMA items: longest first onto the least loaded SIMD
-        // (waves w, w + 4, ... of a workgroup share a SIMD), then onto its least loaded wave
+        // Long horizons apply the operators in block-row low-rank form (fewer MFMAs and fragment
+        // bytes per iteration); short ones keep the dense fragments in registers.
         {
-            struct Item { int grp, rb, cost; };
-            std::vector<Item> items;
-            for (int gi = 0; gi < dev.ngrp; gi++)
-                for (int rb = 0; rb < dev.nrb; rb++) items.push_back({gi, rb, dev.grp_cnt[gi]});
+            const int stride = dev.nwaves * 64 / kTileDev, ncell = sp.nax * (mdl.N + 1);
+            const int cells = (ncell + stride - 1) / stride;
+            const bool in_registers = (six && cells <= 2 && dev.ks <= 16) || (!six && !xy && cells <= 1 && dev.ks <= 21);
+            const int dense_mfma = dev.nrb * dev.ks, lr_mfma = sp.lr_crb * dev.ks + dev.nrb * (4 + sp.lr_uk);
+            dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
+            dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
+        }
+        // deal the MFMA items: longest first onto the least loaded SIMD (waves w, w + 4, ... of a
+        // workgroup share a SIMD), then onto its least loaded wave
+        struct Item { int grp, rb, cost; };
+        auto deal = [&](std::vector<Item> items, int *cnt, unsigned char (*grp)[kMaxItems], unsigned char (*rb)[kMaxItems]) -> bool {
             std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
             int simd_load[4] = {0, 0, 0, 0}, wave_load[kAdmmWaves] = {0};
-            for (int w = 0; w < kAdmmWaves; w++) dev.wi_cnt[w] = 0;
+            for (int w = 0; w < kAdmmWaves; w++) cnt[w] = 0;
             for (const Item &it : items) {
                 int sd = 0;
                 for (int k = 1; k < 4; k++) if (simd_load[k] < simd_load[sd]) sd = k;
                 int w = sd;
                 for (int c = sd + 4; c < dev.nwaves; c += 4) if (wave_load[c] < wave_load[w]) w = c;
-                if (dev.wi_cnt[w] >= kMaxItems) return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
-                dev.wi_grp[w][dev.wi_cnt[w]] = (unsigned char)it.grp;
-                dev.wi_rb[w][dev.wi_cnt[w]] = (unsigned char)it.rb;
-                dev.wi_cnt[w]++;
+                if (cnt[w] >= kMaxItems) return false;
+                grp[w][cnt[w]] = (unsigned char)it.grp;
+                rb[w][cnt[w]] = (unsigned char)it.rb;
+                cnt[w]++;
                 simd_load[sd] += it.cost; wave_load[w] += it.cost;
             }
+            return true;
+        };
+        {
+            // dense: (group, row block); low-rank: (group, row block of the stacked C), then (group, tile)
+            std::vector<Item> items, tiles;
+            for (int gi = 0; gi < dev.ngrp; gi++) {
+                for (int rb = 0; rb < (dev.lr ? dev.lr_crb : dev.nrb); rb++) items.push_back({gi, rb, dev.grp_cnt[gi] * dev.ks});
+                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, dev.grp_cnt[gi] * (4 + dev.lr_uk)});
+            }
+            if (!deal(items, dev.wi_cnt, dev.wi_grp, dev.wi_rb) || !deal(tiles, dev.wj_cnt, dev.wj_grp, dev.wj_rb))
+                return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
         }
+        if (dev.lr) {
+            hipFree(d_Mfrag); d_Mfrag = nullptr;
+            if ((rc = upload(sp.Cfrag, &d_Mfrag))) return rc;
+            if ((rc = upload(sp.DUfrag, &d_DUfrag))) return rc;
+        }
+        dev.DUfrag = d_DUfrag;
         dev.Mfrag = d_Mfrag;
         dev.dt = mdl.Ad[1] != 0.0 ? mdl.Ad[1] : mdl.Ad[3];   // Ad(0,1) (triple integrator) or Ad(0,3) (6-DOF)
         dev.c2 = six ? 0.0 : mdl.Ad[2];
@@ -148,7 +174,7 @@ struct DevStage {
         // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
         // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
         // the iterates of the 16 instances still fit the 160 KiB of LDS
-        dev.separate_xt = 1;
+        dev.separate_xt = dev.lr ? 0 : 1;   // the low-rank form writes xt over the rhs, tile by tile
         if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.separate_xt = 0;
         dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
         dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
@@ -159,7 +185,7 @@ struct DevStage {
     }
     void release()
     {
-        hipFree(d_Mfrag); hipFree(d_queue);
+        hipFree(d_Mfrag); hipFree(d_DUfrag); hipFree(d_queue);
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
         hipFree(d_ovm); hipFree(d_warm);
     }
@@ -270,7 +296,7 @@ extern "C" {
 void tg_default_opts(tg_solver_opts *o)
 {
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
-    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0; o->grid_cap = 0;
+    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0; o->grid_cap = 0; o->lowrank = 0;
     for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }

@@ -61,6 +61,14 @@ struct StageProblem {
     std::vector<int> op_of_block;
     std::vector<int> var_ref;              // n_int -> reference variable or -1
     std::vector<double> Mfrag;             // [nops][ceil(nb/16)][ceil(nb/4) + kRingDepth][64]
+    // Block-row low-rank form of the same operators (long horizons).  K is block tridiagonal, so a
+    // tile row of K^-1 outside its 16 x 16 diagonal tile D_I has rank <= 2 D (D integrator states
+    // couple a step to either side): K^-1[I, :] = D_I (+) U_I C_I with U_I 16 x q orthonormal.
+    //   x_I = D_I r_I + U_I (C_I r)
+    // costs ceil(nrb q / 16) nb/4 + nrb (4 + q/4) MFMAs per operator instead of nrb nb/4.
+    int lr_q = 0, lr_crb = 0, lr_uk = 0;   // q = 2 D; row blocks of the stacked C; k-steps of U
+    std::vector<double> Cfrag;             // [nops][lr_crb][ceil(nb/4) + kRingDepth][64]
+    std::vector<double> DUfrag;            // [nops][ceil(nb/16)][4 + lr_uk][64]: D_I then U_I
     double rho_eq = 0;
     double rho_box[kMaxAxes][kMaxSlots] = {}, lb[kMaxAxes][kMaxSlots] = {}, ub[kMaxAxes][kMaxSlots] = {};
     double rho_mx[6] = {0}, ub_mx[6] = {0};
@@ -121,6 +129,53 @@ inline bool spd_inverse(const std::vector<double> &K, int n, std::vector<double>
             Kinv[(size_t)i * n + j] = Kinv[(size_t)j * n + i] = (double)s;
         }
     return true;
+}
+
+// Orthonormal basis U (rows x q, row-major) of the column space of R (rows x cols, row-major) by
+// Gram-Schmidt with column pivoting and one re-orthogonalisation, and C = U' R (q x cols).
+// Directions below tol * (largest column norm) are left as zero columns of U / rows of C.
+inline void column_space(const std::vector<long double> &R, int rows, int cols, int q, long double tol,
+                         std::vector<long double> &U, std::vector<long double> &C)
+{
+    std::vector<long double> W = R;
+    U.assign((size_t)rows * q, 0.0L);
+    C.assign((size_t)q * cols, 0.0L);
+    long double first = 0.0L;
+    for (int k = 0; k < q; k++) {
+        int best = -1; long double bn = 0.0L;
+        for (int j = 0; j < cols; j++) {
+            long double nn = 0.0L;
+            for (int i = 0; i < rows; i++) nn += W[(size_t)i * cols + j] * W[(size_t)i * cols + j];
+            if (nn > bn) { bn = nn; best = j; }
+        }
+        bn = sqrtl(bn);
+        if (k == 0) first = bn;
+        if (best < 0 || !(bn > tol * first) || bn == 0.0L) break;
+        std::vector<long double> u(rows);
+        for (int i = 0; i < rows; i++) u[i] = W[(size_t)i * cols + best];
+        for (int pass = 0; pass < 2; pass++)
+            for (int p2 = 0; p2 < k; p2++) {
+                long double d = 0.0L;
+                for (int i = 0; i < rows; i++) d += U[(size_t)i * q + p2] * u[i];
+                for (int i = 0; i < rows; i++) u[i] -= d * U[(size_t)i * q + p2];
+            }
+        long double nn = 0.0L;
+        for (int i = 0; i < rows; i++) nn += u[i] * u[i];
+        nn = sqrtl(nn);
+        if (!(nn > 0.0L)) break;
+        for (int i = 0; i < rows; i++) { u[i] /= nn; U[(size_t)i * q + k] = u[i]; }
+        for (int j = 0; j < cols; j++) {
+            long double d = 0.0L;
+            for (int i = 0; i < rows; i++) d += u[i] * W[(size_t)i * cols + j];
+            for (int i = 0; i < rows; i++) W[(size_t)i * cols + j] -= d * u[i];
+        }
+    }
+    for (int k = 0; k < q; k++)
+        for (int j = 0; j < cols; j++) {
+            long double d = 0.0L;
+            for (int i = 0; i < rows; i++) d += U[(size_t)i * q + k] * R[(size_t)i * cols + j];
+            C[(size_t)k * cols + j] = d;
+        }
 }
 
 // Built-in multipliers of rho per class of box row (position, velocity, acceleration, input).
@@ -298,22 +353,73 @@ inline bool build_stage(const StageModel &mdl, double rho, double sigma, const d
         if (!(worst <= 1e-9 * scale)) { err = "internal: the XY operator is not symmetric in its two axes"; return false; }
         sp.nops = 2; sp.op_of_block[0] = 0; sp.op_of_block[1] = 1;
     }
-    // operator fragments: Mfrag[op][rb][kk][lane] = Kinv_block[rb*16 + (lane&15)][4*kk + (lane>>4)]
+    // entry (i, j) of operator o (rows / columns past the block are MFMA padding)
+    auto opval = [&](int o, int i, int j) -> double {
+        const int b = xy ? 0 : op_rep[o];
+        const int ri = vref(b, i), rj = vref(b, j);
+        if (ri < 0 || rj < 0) return 0.0;
+        double v = sp.Kinv[(size_t)ri * n + rj];
+        if (xy) {
+            const double f = sp.Kinv[(size_t)ri * n + vref(1, j)];
+            v = 0.5 * (o == 0 ? v + f : v - f);
+        }
+        return v;
+    };
+    // operator fragments: Mfrag[op][rb][kk][lane] = op[rb*16 + (lane&15)][4*kk + (lane>>4)]
     const int nrb = (sp.nb + 15) / 16, ks = (sp.nb + 3) / 4, ksa = ks + kRingDepth;   // zero steps: prefetch overrun
     sp.Mfrag.assign((size_t)sp.nops * nrb * ksa * 64, 0.0);
-    for (int o = 0; o < sp.nops; o++) {
-        const int b = xy ? 0 : op_rep[o];
+    for (int o = 0; o < sp.nops; o++)
         for (int rb = 0; rb < nrb; rb++)
             for (int kk = 0; kk < ks; kk++)
-                for (int lane = 0; lane < 64; lane++) {
-                    int ri = vref(b, rb * 16 + (lane & 15)), rk = vref(b, 4 * kk + (lane >> 4));
-                    double v = (ri >= 0 && rk >= 0) ? sp.Kinv[(size_t)ri * n + rk] : 0.0;
-                    if (xy && ri >= 0 && rk >= 0) {
-                        const double f = sp.Kinv[(size_t)ri * n + vref(1, 4 * kk + (lane >> 4))];
-                        v = 0.5 * (o == 0 ? v + f : v - f);
+                for (int lane = 0; lane < 64; lane++)
+                    sp.Mfrag[(((size_t)o * nrb + rb) * ksa + kk) * 64 + lane] = opval(o, rb * 16 + (lane & 15), 4 * kk + (lane >> 4));
+    // block-row low-rank form; left empty (lr_q = 0) when the computed inverse does not have it to
+    // working precision, and the dense fragments are used
+    {
+        // smoothing ties an input to its neighbours as well: one more coupling variable per side
+        const int q = 2 * (D + (mdl.smoothing ? 1 : 0)), crb = (nrb * q + 15) / 16, uk = (q + 3) / 4;
+        std::vector<double> Cf((size_t)sp.nops * crb * ksa * 64, 0.0), DUf((size_t)sp.nops * nrb * (4 + uk) * 64, 0.0);
+        bool ok = true;
+        for (int o = 0; o < sp.nops && ok; o++) {
+            long double scale = 0.0L;
+            for (int i = 0; i < sp.nb; i++) scale = std::max(scale, (long double)std::fabs(opval(o, i, i)));
+            std::vector<long double> Cst((size_t)nrb * q * sp.nb, 0.0L);   // stacked C, row I*q + k
+            for (int I = 0; I < nrb && ok; I++) {
+                const int r0 = I * 16, rows = std::min(16, sp.nb - r0);
+                std::vector<long double> R((size_t)rows * sp.nb, 0.0L), U, C;
+                for (int i = 0; i < rows; i++)
+                    for (int j = 0; j < sp.nb; j++)
+                        if (j < r0 || j >= r0 + 16) R[(size_t)i * sp.nb + j] = opval(o, r0 + i, j);
+                column_space(R, rows, sp.nb, q, 1e-13L, U, C);
+                long double worst = 0.0L;
+                for (int i = 0; i < rows; i++)
+                    for (int j = 0; j < sp.nb; j++) {
+                        long double v = 0.0L;
+                        for (int k = 0; k < q; k++) v += U[(size_t)i * q + k] * C[(size_t)k * sp.nb + j];
+                        worst = std::max(worst, fabsl(v - R[(size_t)i * sp.nb + j]));
                     }
-                    sp.Mfrag[(((size_t)o * nrb + rb) * ksa + kk) * 64 + lane] = v;
-                }
+                if (!(worst <= 1e-13L * scale)) { ok = false; break; }
+                for (int k = 0; k < q; k++)
+                    for (int j = 0; j < sp.nb; j++) Cst[((size_t)I * q + k) * sp.nb + j] = C[(size_t)k * sp.nb + j];
+                // D_I (4 k-steps over the tile's own columns) followed by U_I (uk k-steps over its q coefficients)
+                for (int kk = 0; kk < 4 + uk; kk++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int i = lane & 15, c = 4 * (kk < 4 ? kk : kk - 4) + (lane >> 4);
+                        double v = 0.0;
+                        if (kk < 4) v = opval(o, r0 + i, r0 + c);
+                        else if (i < rows && c < q) v = (double)U[(size_t)i * q + c];
+                        DUf[(((size_t)o * nrb + I) * (4 + uk) + kk) * 64 + lane] = v;
+                    }
+            }
+            for (int rb = 0; rb < crb && ok; rb++)
+                for (int kk = 0; kk < ks; kk++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int i = rb * 16 + (lane & 15), j = 4 * kk + (lane >> 4);
+                        Cf[(((size_t)o * crb + rb) * ksa + kk) * 64 + lane] =
+                            (i < nrb * q && j < sp.nb) ? (double)Cst[(size_t)i * sp.nb + j] : 0.0;
+                    }
+        }
+        if (ok) { sp.lr_q = q; sp.lr_crb = crb; sp.lr_uk = uk; sp.Cfrag.swap(Cf); sp.DUfrag.swap(DUf); }
     }
     // per-axis, per-slot step sizes and box templates (identical at every step)
     sp.rho_eq = sp.rho_vec[0];
