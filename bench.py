@@ -231,6 +231,14 @@ def main():
     flops_launch = float(iters.sum()) * flops_per_iteration(model, N) / launches_per_step
     if model != "6dof":   # per-stage sizes differ: weight the stage iteration counts
         flops_launch = sum(float(iters[k].sum()) * f for k, f in enumerate(stage_flops_12state(N))) / 3
+    # flops the matrix cores actually execute (2048 per v_mfma_f64_16x16x4_f64, padding rows and
+    # lock-step iterations of finished tile members included as executed work is per tile): the
+    # low-rank operator form executes fewer than the dense product the algorithmic figure counts
+    if model == "6dof":
+        info = [eng.kernel_info()]
+    else:
+        info = [eng.kernel_info(k) for k in ("z", "xy", "yaw")]
+    executed = sum(float(iters[k].sum()) / 16.0 * info[k][0] * 2048.0 for k in range(stages)) / launches_per_step
     # average admm_kernel launch over the timed region: event time / launches (the other kernels of a
     # step -- xy bounds, yaw reference, plant, shift -- are < 1 % of it); the per-launch event pairs
     # taken after the timed region are reported beside it
@@ -263,7 +271,11 @@ def main():
                      "avg_kernel_ms": avg_kernel_ms, "launches_timed": args.steps * launches_per_step,
                      "per_launch_event_ms": per_launch_event_ms,
                      "sustained_mfma_microbench": FP64_MFMA_SUSTAINED_TFLOPS,
-                     "flops_per_launch": flops_launch},
+                     "flops_per_launch": flops_launch,
+                     "operator_form": ["lowrank" if i[1] else "dense" for i in info],
+                     "mfma_per_tile_iteration": [i[0] for i in info],
+                     "executed_mfma_flops_per_launch_at_least": executed,
+                     "executed_frac_at_least": executed / (avg_kernel_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if avg_kernel_ms > 0 else 0.0},
     }
     del out["config"]["model"]
     if not args.no_cpu_baseline and world == 1:

@@ -155,6 +155,10 @@ int tg_mpc6_reset_warm(tg_mpc6 *h);
 int tg_mpc6_dims(const tg_mpc6 *h, int *n, int *m);
 int tg_mpc6_get(const tg_mpc6 *h, int which, double *out);
 double tg_mpc6_rho(const tg_mpc6 *h);
+/* how the solve kernel applies K^-1: v_mfma_f64_16x16x4_f64 instructions per ADMM iteration of a
+ * tile of 16 instances (2048 flop each), and whether the low-rank form is in use (no counterpart
+ * in the reference; for roofline accounting) */
+int tg_mpc6_kernel_info(const tg_mpc6 *h, int *mfma_per_tile_iteration, int *lowrank);
 
 /* ------------------------------------------------------------------ 12-state (class MPC12STATE) */
 typedef struct tg_mpc12 tg_mpc12;
@@ -198,6 +202,7 @@ int tg_mpc12_reset_warm(tg_mpc12 *h);
 int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m);
 int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out);
 double tg_mpc12_rho(const tg_mpc12 *h, int stage);
+int tg_mpc12_kernel_info(const tg_mpc12 *h, int stage, int *mfma_per_tile_iteration, int *lowrank);
 
 /* ------------------------------------------------------------------ closed-loop roll-out */
 /* Plant update with the first control of the horizon, x0 <- A x0 + B u(0), A and B being

@@ -60,6 +60,7 @@ SYMBOLS = {
     "tg_mpc6_dims": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc6_get": (_i, [_vp, _i, _dp]),
     "tg_mpc6_rho": (_d, [_vp]),
+    "tg_mpc6_kernel_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc12_create": (_i, [C.POINTER(Mpc12Params), C.POINTER(SolverOpts), _dp, _i, C.POINTER(_vp)]),
     "tg_mpc12_destroy": (None, [_vp]),
     "tg_mpc12_solve_batch": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _i, _vp]),
@@ -72,6 +73,7 @@ SYMBOLS = {
     "tg_mpc12_dims": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc12_get": (_i, [_vp, _i, _i, _dp]),
     "tg_mpc12_rho": (_d, [_vp, _i]),
+    "tg_mpc12_kernel_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
     "tg_mpc6_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _vp]),
     "tg_mpc12_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _vp]),
     "tg_ref_shift": (_i, [_i, _i, _i, _i, _dp, _vp]),

@@ -189,6 +189,14 @@ struct DevStage {
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
         hipFree(d_ovm); hipFree(d_warm);
     }
+    void kernel_info(int *mfma, int *lowrank) const
+    {
+        int blocks = 0;
+        for (int gi = 0; gi < dev.ngrp; gi++) blocks += dev.grp_cnt[gi];
+        const int per_block = dev.lr ? dev.lr_crb * dev.ks + dev.nrb * (4 + dev.lr_uk) : dev.nrb * dev.ks;
+        if (mfma) *mfma = blocks * per_block;
+        if (lowrank) *lowrank = dev.lr;
+    }
     size_t warm_rows() const
     {
         return (size_t)3 * sp.n_int + (size_t)2 * sp.nax * (sp.mdl.N + 1) * sp.D + (size_t)12 * (sp.mdl.N + 1);
@@ -484,6 +492,12 @@ int tg_mpc6_get(const tg_mpc6 *h, int which, double *out)
     return h->st.get(which, out);
 }
 double tg_mpc6_rho(const tg_mpc6 *h) { return h ? h->st.sp.rho : 0.0; }
+int tg_mpc6_kernel_info(const tg_mpc6 *h, int *mfma, int *lowrank)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    h->st.kernel_info(mfma, lowrank);
+    return TG_OK;
+}
 
 // ================================================================ 12-state
 struct tg_mpc12 {
@@ -776,5 +790,11 @@ int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out)
     return h->st[stage].get(which, out);
 }
 double tg_mpc12_rho(const tg_mpc12 *h, int stage) { return (h && stage >= 1 && stage <= 3) ? h->st[stage].sp.rho : 0.0; }
+int tg_mpc12_kernel_info(const tg_mpc12 *h, int stage, int *mfma, int *lowrank)
+{
+    if (!h || stage < 1 || stage > 3) return fail(TG_E_ARG, "bad argument");
+    h->st[stage].kernel_info(mfma, lowrank);
+    return TG_OK;
+}
 
 } // extern "C"

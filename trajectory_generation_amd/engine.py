@@ -112,6 +112,12 @@ class BatchedMPC6:
     def rho(self):
         return self.lib.tg_mpc6_rho(self._h)
 
+    def kernel_info(self):
+        """(MFMA instructions per ADMM iteration of a 16-instance tile, low-rank form in use)."""
+        n, lr = C.c_int(), C.c_int()
+        capi.check(self.lib.tg_mpc6_kernel_info(self._h, C.byref(n), C.byref(lr)))
+        return n.value, bool(lr.value)
+
     def rho_rows(self):
         """[(per-row rho vector, rho, nx, N)]: the step sizes the solver was built with."""
         return [(self.get(capi.TG_VEC_RHO), self.rho, 6, self.N)]
@@ -223,6 +229,12 @@ class BatchedMPC12:
 
     def rho(self, stage):
         return self.lib.tg_mpc12_rho(self._h, self.STAGES[stage])
+
+    def kernel_info(self, stage):
+        """(MFMA instructions per ADMM iteration of a 16-instance tile, low-rank form in use)."""
+        n, lr = C.c_int(), C.c_int()
+        capi.check(self.lib.tg_mpc12_kernel_info(self._h, self.STAGES[stage], C.byref(n), C.byref(lr)))
+        return n.value, bool(lr.value)
 
     def rho_rows(self):
         N = self.params.N
