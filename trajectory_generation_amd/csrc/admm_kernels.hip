@@ -346,9 +346,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
         // Cells are handled in groups of G: every LDS read of the group is issued before its first
         // LDS write.  The compiler cannot tell that the regions do not overlap, so a write between
-        // two cells' reads would serialise their latencies.  Variants with many cells per thread
-        // have no registers to spare for it.
-        constexpr int G = MIXED ? 2 : (MAXC <= 2 ? MAXC : 1);
+        // two cells' reads would serialise their latencies.  The dense variants with many cells
+        // per thread have no registers to spare for it; the low-rank ones take pairs.
+        constexpr int G = MIXED ? 2 : (MAXC <= 2 ? MAXC : (LR ? 2 : 1));
 #pragma unroll
         for (int c0 = 0; c0 < ((TG_ABLATE & 2) ? 0 : MAXC); c0 += G) {
             double wn[G][D], wo[G][D], rr[G][S], mixc[G][3];
