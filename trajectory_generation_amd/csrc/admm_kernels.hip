@@ -425,6 +425,21 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // those rows after the barrier, so rhs and xt share one vector without another barrier.
             constexpr int PD = kRingDepth;
             const int q = P.lr_q, crb = P.lr_crb, uk = P.lr_uk, srows = nrb * q;
+            // The second stage's items are short (4 + uk MFMAs) and would each wait a full L2
+            // round trip for their fragments: the first item's are requested before stage 1, the
+            // next item's while the current one computes.
+            constexpr int KD = 6;                      // 4 k-steps of D_I + at most 2 of U_I
+            const int njt = P.wj_cnt[wave];
+            double afn[2][KD];
+            auto load_frags = [&](int jt, double *dst) __attribute__((always_inline)) {
+                if (jt < njt) {
+                    const int grp = P.wj_grp[wave][jt], I = P.wj_rb[wave][jt];
+                    const double *fr = P.DUfrag + ((size_t)P.grp_op[grp] * nrb + I) * (4 + uk) * 64 + lane;
+#pragma unroll
+                    for (int kk = 0; kk < KD; kk++) dst[kk] = kk < 4 + uk ? fr[kk * 64] : 0.0;
+                }
+            };
+            load_frags(0, afn[0]);
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
                 if (it < nit) {
@@ -479,24 +494,22 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
             }
             __syncthreads();
-            const int njt = P.wj_cnt[wave];
 #pragma unroll
             for (int jt = 0; jt < MAXIT; jt++) {
                 if (jt < njt) {
+                    if (jt + 1 < MAXIT) load_frags(jt + 1, afn[(jt + 1) & 1]);
+                    const double *af = afn[jt & 1];
                     const int grp = P.wj_grp[wave][jt], I = P.wj_rb[wave][jt];
                     const bool two = PAIR && P.grp_cnt[grp] == 2;
                     const int blk = P.grp_first[grp];
-                    const double *fr = P.DUfrag + ((size_t)P.grp_op[grp] * nrb + I) * (4 + uk) * 64 + lane;
                     double *r0p = v0 + ((size_t)blk * nb + I * 16 + (lane >> 4)) * 16 + (lane & 15);
                     const double *s0p = lds + SB + ((size_t)blk * P.sb_rows + I * q + (lane >> 4)) * 16 + (lane & 15);
                     auto run = [&](auto two_c) __attribute__((always_inline)) {
                         constexpr bool TWO = decltype(two_c)::value;
-                        constexpr int KD = 6;                      // 4 k-steps of D_I + at most 2 of U_I
-                        double af[KD], bf0[KD], bf1[TWO ? KD : 1];
+                        double bf0[KD], bf1[TWO ? KD : 1];
 #pragma unroll
                         for (int kk = 0; kk < KD; kk++) {
                             const bool in = kk < 4 + uk;
-                            af[kk] = in ? fr[kk * 64] : 0.0;
                             const double *b = kk < 4 ? r0p + kk * 64 : s0p + (kk - 4) * 64;
                             bf0[kk] = in ? b[0] : 0.0;
                             if constexpr (TWO) bf1[kk] = in ? b[(size_t)(kk < 4 ? nb : P.sb_rows) * 16] : 0.0;
