@@ -6,7 +6,8 @@
 
 A step is one pass of the hot path over one batch that is already resident in HBM: QP vector
 assembly from (x0, reference) + ADMM solve + trajectory extraction for every instance.
-Default workload: BASELINE.json configs[1], mpc_6dof, 4096 instances, N = 20, eps 1e-3.
+Default workload: mpc_6dof, 4096 instances, N = 20, eps 1e-3 (the configuration the headline
+metric is quoted on).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -26,7 +27,8 @@ WORKLOADS = {
     "mpc_6dof_B4096_N20": ("6dof", 4096, 20, 2),
     "mpc_12state_B4096_N20": ("12state", 4096, 20, 3),
     "mpc_6dof_B32768_N50": ("6dof", 32768, 50, 4),
-    # closed loop (BASELINE.json configs[4]): a step = warm-started solve + plant update + reference shift
+    # closed loop (per-GPU share of the 65536-vehicle, 500-step configuration): a step = warm-started
+    # solve + plant update + reference shift
     "rollout_12state_B8192_N20": ("12state", 8192, 20, 5),
     "rollout_6dof_B8192_N20": ("6dof", 8192, 20, 5),
 }
