@@ -246,6 +246,17 @@ def test_lowrank_operator_form_matches_oracle(tg, oracle, model, N, B, smooth):
     assert np.abs(r["X"][ok] - rd["X"][ok]).max() < 1e-8
 
 
+def test_kernel_info_reports_operator_form(tg):
+    """Short horizons keep the dense operators (in registers), long ones take the low-rank form
+    unless told otherwise; the MFMA counts per tile-iteration follow from the block sizes."""
+    assert tg.BatchedMPC6(tg.mpc6_params(N=20)).kernel_info() == (3 * 4 * 16, False)
+    n50 = tg.BatchedMPC6(tg.mpc6_params(N=50))
+    assert n50.kernel_info() == (3 * (3 * 39 + 10 * 5), True)
+    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(lowrank=-1)).kernel_info() == (3 * 10 * 39, False)
+    e12 = tg.BatchedMPC12(tg.mpc12_params(N=20))
+    assert [e12.kernel_info(k) for k in ("z", "xy", "yaw")] == [(126, False), (252, False), (126, False)]
+
+
 def test_12state_stage_by_stage_with_injected_upstream(tg, oracle, golden_dir):
     """Each stage solved on the GPU with the certified upstream solution injected (the XY bounds
     are a discontinuous function of the Z solution, so stages are compared one at a time)."""
