@@ -57,20 +57,26 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
     return d == 0 ? 1.0 : (d == 1 ? dt : c2);
 }
 
-// A workgroup is NT threads (8 or 4 waves): thread (g = tid / 16, t = tid % 16) owns the cells
-// g, g + NT/16, ... of instance t.  With 4 waves two workgroups share a CU and the hardware
-// overlaps the MFMA phase of one with the projection phase of the other.  The MFMA work is cut into items (block group, row block)
-// dealt to the waves by the host (StageDev::wi_*), at most MAXIT per wave.
+// A workgroup is NT threads (8 waves): thread (g = tid / 16, t = tid % 16) owns up to MAXC cells of
+// instance slot t -- cells g, g + NT/16, ... of the stage, or, in the two-axis stage (MIXED), both
+// axes' cells of steps g, g + NT/16, ...  The MFMA work is cut into items dealt to the waves by the
+// host (StageDev::wi_*, wj_*), at most MAXIT per wave and stage of the product.
+// PAIR:  two adjacent blocks may share an operator (6-DOF x / y): one fragment load, two accumulators.
 // KSREG > 0: the operator fragments of the wave's single item stay in registers for the whole
-// solve (needs MAXIT == 1 and ks <= KSREG); KSREG == 0: they are streamed from L2.
+//        solve (needs MAXIT == 1 and ks <= KSREG); KSREG == 0: they are streamed from L2.
+// SEP:   rhs and xt live in separate LDS vectors, results are stored as soon as an item is done.
+// LR:    the operators are applied as diagonal tiles + block-row low-rank rest (two stages, one
+//        vector for rhs and xt; needs KSREG == 0 and !SEP).
 //
 // LDS regions, all [rows][16 instances] of doubles, addressed by absolute double index:
 //   V0  rhs of the linear solve            n_int + S rows (the last S rows take the writes of
 //   VX  xt, and x during a check           n_int + S rows  a thread's unused cell slots)
 //   WEQ w = rho z - y of the dynamics rows ncell*D + D rows
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
+//   SB  LR: C r of every block             blocks * sb_rows rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
 //   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
+//   CTAB per axis and slot: step size, lower and upper bound; then the reduction scratch
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
