@@ -114,7 +114,24 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int grp_r = P.wi_grp[wave][0], rb_r = P.wi_rb[wave][0];
     const bool two_r = PAIR && P.grp_cnt[grp_r] == 2;
     const int boff_r = (P.grp_first[grp_r] * nb + (lane >> 4)) * 16 + (lane & 15);
-    if constexpr (KSREG > 0) {
+    // LR with register-resident fragments (short horizons): C r is formed as four partial sums,
+    // one quarter of the k range per first-stage item, so that eight items fill the eight waves;
+    // the second stage applies U_I to each partial: xt_I = D_I r_I + sum_p U_I s_I^(p).  A wave
+    // holds the KQ fragments of its (group, part) and the 5 of its (group, tile).
+    constexpr bool LRK = LR && KSREG > 0;
+    constexpr int KQ = LRK ? KSREG / 4 : 1;
+    double creg[KQ], dreg[LRK ? 5 : 1];
+    const int grp_2 = P.wj_grp[wave][0], tile_2 = P.wj_rb[wave][0];
+    if constexpr (LRK) {
+        const bool has1 = nit > 0, has2 = P.wj_cnt[wave] > 0;
+#pragma unroll
+        for (int kk = 0; kk < KQ; kk++) {
+            const int k = rb_r * KQ + kk;              // rb_r: the part of the k range
+            creg[kk] = (has1 && k < ks) ? P.Mfrag[((size_t)P.grp_op[grp_r] * P.ks_alloc + k) * 64 + lane] : 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 5; kk++) dreg[kk] = has2 ? P.DUfrag[(((size_t)P.grp_op[grp_2] * nrb + tile_2) * 5 + kk) * 64 + lane] : 0.0;
+    } else if constexpr (KSREG > 0) {
         const int grp = grp_r, rb = rb_r;
 #pragma unroll
         for (int kk = 0; kk < KSREG; kk++) {
@@ -128,7 +145,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int WEQ = (SEP ? 2 : 1) * (n_int + S) * 16;
     const int WMX = WEQ + (ncell * D + D) * 16;
     const int SB = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);                   // LR: C r of every block, [blocks][sb_rows][16]
-    const int ZERO = SB + (LR ? (n_int / nb) * P.sb_rows * 16 : 0);
+    const int ZERO = SB + (LR ? P.lr_np * (n_int / nb) * P.sb_rows * 16 : 0);
     const int BGT = ZERO + 8 * 16;                                           // [NAX][D][16] -x0: l = u of the step-0 rows
     const int CTAB = BGT + NAX * D * 16;                                     // [NAX][S][3] rho, lb, ub
     unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
@@ -424,7 +441,80 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
         // D[16 rows x 16 instances] += A[16 x 4] * B[4 x 16]: A = operator fragment (registers
         // when it fits, else streamed from L2 through a prefetch ring), B = rhs rows from LDS
-        if constexpr (LR) {
+        if constexpr (LRK) {
+            const int nblk = n_int / nb;
+            const size_t pstride = (size_t)nblk * P.sb_rows * 16;      // doubles between partial sums
+            {   // stage 1: this wave's quarter of C r
+                const int blk = P.grp_first[grp_r];
+                const double *bp0 = v0 + ((size_t)blk * nb + 4 * rb_r * KQ + (lane >> 4)) * 16 + (lane & 15);
+                auto run = [&](auto two_c) __attribute__((always_inline)) {
+                    constexpr bool TWO = decltype(two_c)::value;
+                    double bf0[KQ], bf1[TWO ? KQ : 1];
+#pragma unroll
+                    for (int kk = 0; kk < KQ; kk++) {
+                        bf0[kk] = bp0[kk * 64];
+                        if constexpr (TWO) bf1[kk] = bp0[(size_t)nb * 16 + kk * 64];
+                    }
+                    d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+#pragma unroll
+                    for (int kk = 0; kk < KQ; kk++) {
+                        if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(creg[kk], bf0[kk], c0, 0, 0, 0);
+                        else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(creg[kk], bf0[kk], c1, 0, 0, 0);
+                        if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(creg[kk], bf1[kk], c1, 0, 0, 0);
+                    }
+                    if constexpr (!TWO) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) c0[r] += c1[r];
+                    }
+                    double *o0 = lds + SB + rb_r * pstride + ((size_t)blk * P.sb_rows + (lane >> 4)) * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o0[r * 64] = c0[r];
+                    if constexpr (TWO) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o0[(size_t)P.sb_rows * 16 + r * 64] = c1[r];
+                    }
+                };
+                if (nit > 0) { if (PAIR && two_r) run(std::true_type{}); else run(std::false_type{}); }
+            }
+            __syncthreads();
+            {   // stage 2: this wave's tile, D_I r_I + U_I (s^(0) + ... + s^(3)) applied term by term
+                const int blk = P.grp_first[grp_2];
+                const bool two = PAIR && P.grp_cnt[grp_2] == 2;
+                const double *r0p = v0 + ((size_t)blk * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
+                const double *s0p = lds + SB + ((size_t)blk * P.sb_rows + tile_2 * P.lr_q + (lane >> 4)) * 16 + (lane & 15);
+                auto run = [&](auto two_c) __attribute__((always_inline)) {
+                    constexpr bool TWO = decltype(two_c)::value;
+                    double bf0[8], bf1[TWO ? 8 : 1];
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++) {
+                        const double *b = kk < 4 ? r0p + kk * 64 : s0p + (kk - 4) * pstride;
+                        bf0[kk] = b[0];
+                        if constexpr (TWO) bf1[kk] = b[(size_t)(kk < 4 ? nb : P.sb_rows) * 16];
+                    }
+                    d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++) {
+                        const double af = dreg[kk < 4 ? kk : 4];
+                        if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf0[kk], c0, 0, 0, 0);
+                        else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf0[kk], c1, 0, 0, 0);
+                        if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf1[kk], c1, 0, 0, 0);
+                    }
+                    if constexpr (!TWO) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) c0[r] += c1[r];
+                    }
+                    double *o0 = vx + ((size_t)blk * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
+                    const int row0 = tile_2 * 16 + (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[r * 64] = c0[r];
+                    if constexpr (TWO) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[(size_t)nb * 16 + r * 64] = c1[r];
+                    }
+                };
+                if (P.wj_cnt[wave] > 0) { if (PAIR && two) run(std::true_type{}); else run(std::false_type{}); }
+            }
+        } else if constexpr (LR) {
             // Block-row low-rank form: stage 1, s = C r for every block (the stacked C streams from
             // L2 like a dense operator with few rows); stage 2, per 16-row tile I,
             // xt_I = D_I r_I + U_I s_I written over r_I: only the tile's own wave reads or writes
@@ -1210,7 +1300,7 @@ size_t admm_lds_bytes(const StageDev &P)
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
                   (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D +
-                  (P.lr ? (size_t)(P.n_int / P.nb) * P.sb_rows : 0);
+                  (P.lr ? (size_t)P.lr_np * (P.n_int / P.nb) * P.sb_rows : 0);
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves + 1) * 16 * sizeof(double);
 }
 
@@ -1295,6 +1385,14 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     single.separate_xt = 0;
     int needj = 0;
     for (int w = 0; w < P.nwaves; w++) needj = P.wj_cnt[w] > needj ? P.wj_cnt[w] : needj;
+    if (P.lr && P.lr_np == 4) {
+        // low-rank operators with register-resident fragments (6-DOF, short horizons)
+        if (P.D == 2 && P.nax == 3 && !P.mixed && sym && sep && needc <= 2 && needi <= 1 && needj <= 1 && fits(16) &&
+            P.lr_crb == 1 && P.lr_uk == 1)
+            return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(P, a, s);
+        *why = "internal: no register-resident low-rank variant for this stage";
+        return hipErrorInvalidValue;
+    }
     if (P.lr) {
         // block-row low-rank operators: rhs and xt share one vector
         if (sep) { *why = "internal: the low-rank form keeps rhs and xt in one vector"; return hipErrorInvalidValue; }

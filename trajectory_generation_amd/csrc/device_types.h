@@ -36,6 +36,7 @@ struct StageDev {
     // DUfrag the tiles' D_I and U_I ([nops][nrb][4 + lr_uk][64]; wj_* items are (group, tile)).
     int lr, lr_q, lr_crb, lr_uk;
     int sb_rows;                 // LDS rows per block for C r: lr_crb * 16 + 8
+    int lr_np;                   // partial sums C r is formed as: 1 (streamed form) or 4 (register-resident form)
     const double *DUfrag;
     int wj_cnt[kAdmmWaves];
     unsigned char wj_grp[kAdmmWaves][kMaxItems], wj_rb[kAdmmWaves][kMaxItems];

@@ -115,6 +115,15 @@ struct DevStage {
             const int dense_mfma = dev.nrb * dev.ks, lr_mfma = sp.lr_crb * dev.ks + dev.nrb * (4 + sp.lr_uk);
             dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
             dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
+            dev.lr_np = 1;
+            // short 6-DOF horizons: the low-rank form with register-resident fragments and C r as
+            // four partial sums (one first-stage item per wave)
+            // (its B-operand reads run up to 64 rows past the start of the last block: they must
+            // stay inside the zero-initialised LDS, as launch_admm checks)
+            const int S = sp.D + 1;
+            const int rows_init = 2 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
+            if (lowrank_mode >= 0 && six && in_registers && sp.lr_q == 4 && sp.lr_crb == 1 && sp.lr_uk == 1 &&
+                (sp.n_int - sp.nb) + 64 <= rows_init) { dev.lr = 1; dev.lr_np = 4; }
         }
         // deal the MFMA items: longest first onto the least loaded SIMD (waves w, w + 4, ... of a
         // workgroup share a SIMD), then onto its least loaded wave
@@ -140,8 +149,12 @@ struct DevStage {
             // dense: (group, row block); low-rank: (group, row block of the stacked C), then (group, tile)
             std::vector<Item> items, tiles;
             for (int gi = 0; gi < dev.ngrp; gi++) {
-                for (int rb = 0; rb < (dev.lr ? dev.lr_crb : dev.nrb); rb++) items.push_back({gi, rb, dev.grp_cnt[gi] * dev.ks});
-                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, dev.grp_cnt[gi] * (4 + dev.lr_uk)});
+                if (dev.lr && dev.lr_np == 4) {   // (group, quarter of the k range)
+                    for (int pt = 0; pt < 4; pt++) items.push_back({gi, pt, dev.grp_cnt[gi] * 4});
+                } else {
+                    for (int rb = 0; rb < (dev.lr ? dev.lr_crb : dev.nrb); rb++) items.push_back({gi, rb, dev.grp_cnt[gi] * dev.ks});
+                }
+                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, dev.grp_cnt[gi] * (4 + dev.lr_np * dev.lr_uk)});
             }
             if (!deal(items, dev.wi_cnt, dev.wi_grp, dev.wi_rb) || !deal(tiles, dev.wj_cnt, dev.wj_grp, dev.wj_rb))
                 return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
@@ -174,7 +187,7 @@ struct DevStage {
         // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
         // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
         // the iterates of the 16 instances still fit the 160 KiB of LDS
-        dev.separate_xt = dev.lr ? 0 : 1;   // the low-rank form writes xt over the rhs, tile by tile
+        dev.separate_xt = (dev.lr && dev.lr_np == 1) ? 0 : 1;   // the streamed low-rank form writes xt over the rhs, tile by tile
         if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.separate_xt = 0;
         dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
         dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
@@ -193,7 +206,7 @@ struct DevStage {
     {
         int blocks = 0;
         for (int gi = 0; gi < dev.ngrp; gi++) blocks += dev.grp_cnt[gi];
-        const int per_block = dev.lr ? dev.lr_crb * dev.ks + dev.nrb * (4 + dev.lr_uk) : dev.nrb * dev.ks;
+        const int per_block = dev.lr ? (dev.lr_np == 4 ? 16 : dev.lr_crb * dev.ks) + dev.nrb * (4 + dev.lr_np * dev.lr_uk) : dev.nrb * dev.ks;
         if (mfma) *mfma = blocks * per_block;
         if (lowrank) *lowrank = dev.lr;
     }
