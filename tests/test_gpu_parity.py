@@ -250,7 +250,7 @@ def test_kernel_info_reports_operator_form(tg):
     """6-DOF stages take the low-rank form (register resident with four partial sums at short
     horizons, streamed at long ones) unless told otherwise, the short 12-state stages the dense
     one; the MFMA counts per tile-iteration follow from the block sizes."""
-    assert tg.BatchedMPC6(tg.mpc6_params(N=20)).kernel_info() == (3 * (16 + 4 * 8), True)
+    assert tg.BatchedMPC6(tg.mpc6_params(N=20)).kernel_info() == (3 * (16 + 4 * 5), True)
     assert tg.BatchedMPC6(tg.mpc6_params(N=20), tg.make_opts(lowrank=-1)).kernel_info() == (3 * 4 * 16, False)
     assert tg.BatchedMPC6(tg.mpc6_params(N=20, enable_control_smoothing=True)).kernel_info() == (3 * 4 * 16, False)
     n50 = tg.BatchedMPC6(tg.mpc6_params(N=50))

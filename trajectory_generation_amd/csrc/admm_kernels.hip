@@ -116,7 +116,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int boff_r = (P.grp_first[grp_r] * nb + (lane >> 4)) * 16 + (lane & 15);
     // LR with register-resident fragments (short horizons): C r is formed as four partial sums,
     // one quarter of the k range per first-stage item, so that eight items fill the eight waves;
-    // the second stage applies U_I to each partial: xt_I = D_I r_I + sum_p U_I s_I^(p).  A wave
+    // the second stage adds the partials and applies U_I: xt_I = D_I r_I + U_I sum_p s_I^(p).  A wave
     // holds the KQ fragments of its (group, part) and the 5 of its (group, tile).
     constexpr bool LRK = LR && KSREG > 0;
     constexpr int KQ = LRK ? KSREG / 4 : 1;
@@ -477,27 +477,29 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (nit > 0) { if (PAIR && two_r) run(std::true_type{}); else run(std::false_type{}); }
             }
             __syncthreads();
-            {   // stage 2: this wave's tile, D_I r_I + U_I (s^(0) + ... + s^(3)) applied term by term
+            {   // stage 2: this wave's tile, D_I r_I + U_I (s^(0) + ... + s^(3))
                 const int blk = P.grp_first[grp_2];
                 const bool two = PAIR && P.grp_cnt[grp_2] == 2;
                 const double *r0p = v0 + ((size_t)blk * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
                 const double *s0p = lds + SB + ((size_t)blk * P.sb_rows + tile_2 * P.lr_q + (lane >> 4)) * 16 + (lane & 15);
                 auto run = [&](auto two_c) __attribute__((always_inline)) {
                     constexpr bool TWO = decltype(two_c)::value;
-                    double bf0[8], bf1[TWO ? 8 : 1];
+                    // the four partial sums of the tile's coefficients are added on the way in
+                    double bf0[5], bf1[TWO ? 5 : 1], sp0[4], sp1[TWO ? 4 : 1];
 #pragma unroll
-                    for (int kk = 0; kk < 8; kk++) {
-                        const double *b = kk < 4 ? r0p + kk * 64 : s0p + (kk - 4) * pstride;
-                        bf0[kk] = b[0];
-                        if constexpr (TWO) bf1[kk] = b[(size_t)(kk < 4 ? nb : P.sb_rows) * 16];
+                    for (int kk = 0; kk < 4; kk++) {
+                        bf0[kk] = r0p[kk * 64];
+                        sp0[kk] = s0p[kk * pstride];
+                        if constexpr (TWO) { bf1[kk] = r0p[(size_t)nb * 16 + kk * 64]; sp1[kk] = s0p[(size_t)P.sb_rows * 16 + kk * pstride]; }
                     }
+                    bf0[4] = (sp0[0] + sp0[1]) + (sp0[2] + sp0[3]);
+                    if constexpr (TWO) bf1[4] = (sp1[0] + sp1[1]) + (sp1[2] + sp1[3]);
                     d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
 #pragma unroll
-                    for (int kk = 0; kk < 8; kk++) {
-                        const double af = dreg[kk < 4 ? kk : 4];
-                        if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf0[kk], c0, 0, 0, 0);
-                        else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf0[kk], c1, 0, 0, 0);
-                        if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af, bf1[kk], c1, 0, 0, 0);
+                    for (int kk = 0; kk < 5; kk++) {
+                        if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf0[kk], c0, 0, 0, 0);
+                        else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf0[kk], c1, 0, 0, 0);
+                        if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf1[kk], c1, 0, 0, 0);
                     }
                     if constexpr (!TWO) {
 #pragma unroll

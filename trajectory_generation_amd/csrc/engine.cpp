@@ -154,7 +154,7 @@ struct DevStage {
                 } else {
                     for (int rb = 0; rb < (dev.lr ? dev.lr_crb : dev.nrb); rb++) items.push_back({gi, rb, dev.grp_cnt[gi] * dev.ks});
                 }
-                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, dev.grp_cnt[gi] * (4 + dev.lr_np * dev.lr_uk)});
+                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, dev.grp_cnt[gi] * (4 + dev.lr_uk)});
             }
             if (!deal(items, dev.wi_cnt, dev.wi_grp, dev.wi_rb) || !deal(tiles, dev.wj_cnt, dev.wj_grp, dev.wj_rb))
                 return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
@@ -206,7 +206,7 @@ struct DevStage {
     {
         int blocks = 0;
         for (int gi = 0; gi < dev.ngrp; gi++) blocks += dev.grp_cnt[gi];
-        const int per_block = dev.lr ? (dev.lr_np == 4 ? 16 : dev.lr_crb * dev.ks) + dev.nrb * (4 + dev.lr_np * dev.lr_uk) : dev.nrb * dev.ks;
+        const int per_block = dev.lr ? (dev.lr_np == 4 ? 16 : dev.lr_crb * dev.ks) + dev.nrb * (4 + dev.lr_uk) : dev.nrb * dev.ks;
         if (mfma) *mfma = blocks * per_block;
         if (lowrank) *lowrank = dev.lr;
     }
