@@ -159,6 +159,17 @@ double tg_mpc6_rho(const tg_mpc6 *h);
  * tile of 16 instances (2048 flop each), and whether the low-rank form is in use (no counterpart
  * in the reference; for roofline accounting) */
 int tg_mpc6_kernel_info(const tg_mpc6 *h, int *mfma_per_tile_iteration, int *lowrank);
+/* Solver settings of a live handle (what osqp-eigen's solver.settings() exposes,
+ * mpc_6dof.cpp:527-528): get returns the effective values (automatic rho / rho_scale resolved,
+ * lowrank = the operator form in use); set changes alpha, eps_*, max_iter, check_termination,
+ * check_fine and grid_cap for the following solves.  rho, sigma and rho_scale enter the
+ * factorised operator and are frozen at create: asking for different ones returns TG_E_STATE. */
+int tg_mpc6_get_opts(const tg_mpc6 *h, tg_solver_opts *out);
+int tg_mpc6_set_opts(tg_mpc6 *h, const tg_solver_opts *o);
+/* Unscaled primal / dual residual (OSQP's info->pri_res, dua_res) of instances [0, B) at the
+ * termination check that ended the handle's last solve; host arrays of B doubles, either may be
+ * NULL.  Synchronises the device. */
+int tg_mpc6_last_residuals(tg_mpc6 *h, int B, double *prim, double *dual);
 
 /* ------------------------------------------------------------------ 12-state (class MPC12STATE) */
 typedef struct tg_mpc12 tg_mpc12;
@@ -203,14 +214,24 @@ int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m);
 int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out);
 double tg_mpc12_rho(const tg_mpc12 *h, int stage);
 int tg_mpc12_kernel_info(const tg_mpc12 *h, int stage, int *mfma_per_tile_iteration, int *lowrank);
+/* as for the 6-DOF handle; get is per stage (their rho differ), set applies to all three */
+int tg_mpc12_get_opts(const tg_mpc12 *h, int stage, tg_solver_opts *out);
+int tg_mpc12_set_opts(tg_mpc12 *h, const tg_solver_opts *o);
+int tg_mpc12_last_residuals(tg_mpc12 *h, int stage, int B, double *prim, double *dual);
 
 /* ------------------------------------------------------------------ closed-loop roll-out */
 /* Plant update with the first control of the horizon, x0 <- A x0 + B u(0), A and B being
  * getTransitionMatrix / getInputMatrix: the rule both test mains roll the solution out with
  * (test_mpc_6dof.cpp:115-122, test_mpc_12state.cpp:193-197; mpc_12state.cpp:2001-2025).
- * d_x0 [nx][ld] is updated in place, d_U is the U array of the last solve (rows 0..nu-1 used). */
-int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, const double *d_U, void *stream);
-int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, const double *d_U, void *stream);
+ * d_x0 [nx][ld] is updated in place, d_U is the U array of the last solve.
+ * d_status: the status array of that solve ([ld], 12-state [3][ld]) or NULL.  An instance whose
+ * solve did not reach TG_SOLVED in every stage got no new plan -- mpcLoop returned false and the
+ * reference's node publishes nothing (mpc_ros.cpp:428-432, mpc_12state_ros.cpp:519-527) -- so it
+ * keeps following the last plan it received: its U rows move one step up (zeros enter at the end:
+ * beyond the plan it coasts) before row 0 is applied.  With NULL every instance counts as solved.
+ * 12-state: a stage that did solve has already written its own rows of X / U. */
+int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, double *d_U, const int *d_status, void *stream);
+int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, double *d_U, const int *d_status, void *stream);
 /* Receding horizon on a reference array ref [nx(N+1)][ld]: block i+1 moves to block i, the last
  * block is continued linearly.  What mpc_ros.cpp / mpc_12state_ros.cpp get from their reference
  * topic at every step, produced on the device. */
@@ -221,11 +242,11 @@ int tg_ref_shift(int B, int ld, int nx, int N, double *d_ref, void *stream);
 int tg_copy_to_host(void *dst, const void *d_src, unsigned long long bytes);
 
 /* ------------------------------------------------------------------ kernel timing hook */
-/* Average duration (ms) and launch count of the ADMM kernel over the launches made since
- * the last call with reset != 0; measured with HIP events on the launch stream when
- * timing is enabled.  Used by the benchmark's roofline line. */
+/* Total duration (ms) and number of the ADMM kernel launches made while timing was enabled,
+ * since the last call with reset != 0, over all handles of the process; measured with HIP events
+ * on each launch's stream.  Used by the benchmark's roofline line.  Thread-safe. */
 void tg_timing_enable(int on);
-int tg_timing_read(double *admm_ms_total, int *admm_launches, double *iters_total, int reset);
+int tg_timing_read(double *admm_ms_total, int *admm_launches, int reset);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,11 @@ typedef struct {
                                       check_termination) test every check_fine iterations, so the
                                       checker can follow the engine's check schedule; 0 = OSQP's
                                       fixed interval */
+    int    linsys;                 /* NOT an OSQP setting: 0 = dense Cholesky of the reduced matrix
+                                      P + sigma I + A' rho A (what the parity tests compare the
+                                      engine with), 1 = sparse LDL' of the quasi-definite KKT
+                                      matrix, the form of OSQP's default linear-system solver and
+                                      of the CPU baseline timing */
 } osqp_settings;
 
 enum {

@@ -35,7 +35,7 @@ class Settings(C.Structure):
                 ("max_iter", C.c_int), ("check_termination", C.c_int), ("scaling", C.c_int),
                 ("adaptive_rho", C.c_int), ("adaptive_rho_interval", C.c_int),
                 ("adaptive_rho_tolerance", C.c_double), ("warm_start", C.c_int),
-                ("scaled_termination", C.c_int), ("check_fine", C.c_int)]
+                ("scaled_termination", C.c_int), ("check_fine", C.c_int), ("linsys", C.c_int)]
 
 
 class Mpc6Params(C.Structure):

@@ -12,7 +12,12 @@
  * solver's documented constants.  The linear system is solved in its reduced form
  *   (P + sigma I + A' diag(rho) A) xt = sigma x - q + A'(rho z - y),   zt = A xt
  * by a dense Cholesky factorisation; this is algebraically the quasi-definite KKT solve
- * of the paper with nu eliminated.
+ * of the paper with nu eliminated.  settings.linsys = 1 solves the quasi-definite system itself,
+ *   [P + sigma I, A'; A, -diag(1/rho)] [xt; nu] = [sigma x - q; z - y/rho],  zt = z + (nu - y)/rho,
+ * with a sparse LDL' factorisation (fill-reducing minimum-degree ordering, elimination tree,
+ * up-looking numeric factorisation) as OSQP's default linear-system solver does on the sparse
+ * matrices the reference hands it (sparseView(), mpc_6dof.cpp:532-536); it is the form the CPU
+ * baseline is timed in.
  */
 #include "mpc_oracle.h"
 #include <math.h>
@@ -33,8 +38,20 @@ typedef struct {
     double *val;
 } csr;
 
+/* sparse LDL' of the permuted quasi-definite KKT matrix */
+typedef struct {
+    int N;                 /* n + m */
+    int *perm, *iperm;     /* perm[new] = old */
+    int *Kp, *Ki;          /* upper triangle, column-compressed, permuted */
+    double *Kx;
+    int *rho_slot;         /* position in Kx of the -1/rho entry of constraint i */
+    int *parent, *Lnz, *Lp, *Li, *flag, *pattern;
+    double *Lx, *D, *Y, *b;
+} kkt_ldl;
+
 struct osqp_work {
     int n, m;
+    kkt_ldl *kkt;
     osqp_settings s;
     csr P, A, At;          /* scaled data */
     double *q, *l, *u;     /* scaled */
@@ -43,6 +60,7 @@ struct osqp_work {
     double *rho_scale;     /* optional per-row multiplier of rho on inequality rows (NULL: 1) */
     int *constr_type;
     double *L;             /* dense Cholesky factor of the reduced matrix, n x n lower */
+    double *kkt_rhs;       /* linsys = 1: right-hand side / solution of the KKT system, n + m */
     double *x, *z, *y, *x_prev, *z_prev, *xt, *zt, *delta_x, *delta_y;
     double *Ax, *Px, *Aty, *wn, *wm;
     double *sol_x, *sol_y;
@@ -134,6 +152,7 @@ void osqp_default_settings(osqp_settings *s)
     s->scaling = 10; s->adaptive_rho = 1; s->adaptive_rho_interval = 0;
     s->adaptive_rho_tolerance = 5.0; s->warm_start = 1; s->scaled_termination = 0;
     s->check_fine = 0;
+    s->linsys = 0;
 }
 
 void osqp_fixed_rho_settings(osqp_settings *s, double rho)
@@ -213,8 +232,11 @@ static void apply_rho(osqp_work *w)
     }
 }
 
+static int kkt_numeric(osqp_work *w);
+
 static int factor(osqp_work *w)
 {
+    if (w->kkt) return kkt_numeric(w);
     int n = w->n;
     double *K = w->L;
     memset(K, 0, sizeof(double) * (size_t)n * n);
@@ -262,6 +284,196 @@ static void chol_solve(const osqp_work *w, double *b)
     }
 }
 
+
+/* ---------------------------------------------------------------- sparse KKT LDL' (linsys = 1) */
+typedef struct { int i, j; double v; int rho_of; } trip;
+
+static int trip_cmp(const void *a, const void *b)
+{
+    const trip *x = (const trip *)a, *y = (const trip *)b;
+    if (x->j != y->j) return x->j < y->j ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);
+}
+
+/* greedy minimum-degree ordering of a symmetric pattern given as bit rows (adj[v] has bit u set) */
+static void min_degree_order(int N, unsigned long long *adj, int words, int *perm)
+{
+    char *gone = (char *)calloc((size_t)N, 1);
+    int *deg = (int *)calloc((size_t)N, sizeof(int));
+    for (int v = 0; v < N; v++) {
+        int d = 0;
+        for (int k = 0; k < words; k++) d += __builtin_popcountll(adj[(size_t)v * words + k]);
+        deg[v] = d;
+    }
+    for (int step = 0; step < N; step++) {
+        int best = -1;
+        for (int v = 0; v < N; v++) if (!gone[v] && (best < 0 || deg[v] < deg[best])) best = v;
+        perm[step] = best;
+        gone[best] = 1;
+        const unsigned long long *av = adj + (size_t)best * words;
+        for (int k = 0; k < words; k++) {
+            unsigned long long bits = av[k];
+            while (bits) {
+                int u = k * 64 + __builtin_ctzll(bits);
+                bits &= bits - 1;
+                unsigned long long *au = adj + (size_t)u * words;
+                int d = 0;
+                for (int q = 0; q < words; q++) au[q] |= av[q];
+                au[best >> 6] &= ~(1ull << (best & 63));
+                au[u >> 6] &= ~(1ull << (u & 63));
+                for (int q = 0; q < words; q++) d += __builtin_popcountll(au[q]);
+                deg[u] = d;
+            }
+        }
+    }
+    free(gone); free(deg);
+}
+
+static void kkt_free(kkt_ldl *k)
+{
+    if (!k) return;
+    free(k->perm); free(k->iperm); free(k->Kp); free(k->Ki); free(k->Kx); free(k->rho_slot);
+    free(k->parent); free(k->Lnz); free(k->Lp); free(k->Li); free(k->flag); free(k->pattern);
+    free(k->Lx); free(k->D); free(k->Y); free(k->b);
+    free(k);
+}
+
+static int kkt_setup(osqp_work *w)
+{
+    const int n = w->n, m = w->m, N = n + m;
+    kkt_ldl *k = (kkt_ldl *)calloc(1, sizeof(kkt_ldl));
+    k->N = N;
+    /* entries of the upper triangle in the original ordering */
+    int cap = w->P.nnz + n + w->A.nnz + m, cnt = 0;
+    trip *t = (trip *)calloc((size_t)cap, sizeof(trip));
+    char *has_diag = (char *)calloc((size_t)n, 1);
+    for (int i = 0; i < n; i++)
+        for (int p = w->P.ptr[i]; p < w->P.ptr[i + 1]; p++) {
+            int j = w->P.idx[p];
+            if (j < i) continue;
+            double v = w->P.val[p];
+            if (j == i) { v += w->s.sigma; has_diag[i] = 1; }
+            t[cnt].i = i; t[cnt].j = j; t[cnt].v = v; t[cnt].rho_of = -1; cnt++;
+        }
+    for (int i = 0; i < n; i++)
+        if (!has_diag[i]) { t[cnt].i = i; t[cnt].j = i; t[cnt].v = w->s.sigma; t[cnt].rho_of = -1; cnt++; }
+    for (int r = 0; r < m; r++) {
+        for (int p = w->A.ptr[r]; p < w->A.ptr[r + 1]; p++) {
+            t[cnt].i = w->A.idx[p]; t[cnt].j = n + r; t[cnt].v = w->A.val[p]; t[cnt].rho_of = -1; cnt++;
+        }
+        t[cnt].i = n + r; t[cnt].j = n + r; t[cnt].v = -w->rho_inv_vec[r]; t[cnt].rho_of = r; cnt++;
+    }
+    free(has_diag);
+    /* ordering */
+    const int words = (N + 63) / 64;
+    unsigned long long *adj = (unsigned long long *)calloc((size_t)N * words, sizeof(unsigned long long));
+    for (int e = 0; e < cnt; e++)
+        if (t[e].i != t[e].j) {
+            adj[(size_t)t[e].i * words + (t[e].j >> 6)] |= 1ull << (t[e].j & 63);
+            adj[(size_t)t[e].j * words + (t[e].i >> 6)] |= 1ull << (t[e].i & 63);
+        }
+    k->perm = (int *)calloc((size_t)N, sizeof(int));
+    k->iperm = (int *)calloc((size_t)N, sizeof(int));
+    min_degree_order(N, adj, words, k->perm);
+    free(adj);
+    for (int a = 0; a < N; a++) k->iperm[k->perm[a]] = a;
+    /* permuted upper triangle, column-compressed */
+    for (int e = 0; e < cnt; e++) {
+        int a = k->iperm[t[e].i], b = k->iperm[t[e].j];
+        if (a > b) { int c = a; a = b; b = c; }
+        t[e].i = a; t[e].j = b;
+    }
+    qsort(t, (size_t)cnt, sizeof(trip), trip_cmp);
+    k->Kp = (int *)calloc((size_t)N + 1, sizeof(int));
+    k->Ki = (int *)calloc((size_t)cnt, sizeof(int));
+    k->Kx = dalloc(cnt);
+    k->rho_slot = (int *)calloc((size_t)m + 1, sizeof(int));
+    for (int e = 0; e < cnt; e++) {
+        k->Kp[t[e].j + 1]++;
+        k->Ki[e] = t[e].i; k->Kx[e] = t[e].v;
+        if (t[e].rho_of >= 0) k->rho_slot[t[e].rho_of] = e;
+    }
+    for (int j = 0; j < N; j++) k->Kp[j + 1] += k->Kp[j];
+    free(t);
+    /* elimination tree and column counts of L */
+    k->parent = (int *)calloc((size_t)N, sizeof(int));
+    k->Lnz = (int *)calloc((size_t)N, sizeof(int));
+    k->flag = (int *)calloc((size_t)N, sizeof(int));
+    k->pattern = (int *)calloc((size_t)N, sizeof(int));
+    k->Lp = (int *)calloc((size_t)N + 1, sizeof(int));
+    for (int c = 0; c < N; c++) {
+        k->parent[c] = -1; k->flag[c] = c; k->Lnz[c] = 0;
+        for (int p = k->Kp[c]; p < k->Kp[c + 1]; p++) {
+            int i = k->Ki[p];
+            for (; i < c && k->flag[i] != c; i = k->parent[i]) {
+                if (k->parent[i] == -1) k->parent[i] = c;
+                k->Lnz[i]++;
+                k->flag[i] = c;
+            }
+        }
+    }
+    for (int c = 0; c < N; c++) k->Lp[c + 1] = k->Lp[c] + k->Lnz[c];
+    k->Li = (int *)calloc((size_t)(k->Lp[N] > 0 ? k->Lp[N] : 1), sizeof(int));
+    k->Lx = dalloc(k->Lp[N]);
+    k->D = dalloc(N); k->Y = dalloc(N); k->b = dalloc(N);
+    w->kkt = k;
+    return kkt_numeric(w);
+}
+
+/* up-looking LDL': row c of L is the solution of L(0:c-1, 0:c-1) D y = K(0:c-1, c) on the
+ * elimination-tree reach of column c */
+static int kkt_numeric(osqp_work *w)
+{
+    kkt_ldl *k = w->kkt;
+    const int N = k->N;
+    for (int r = 0; r < w->m; r++) k->Kx[k->rho_slot[r]] = -w->rho_inv_vec[r];
+    for (int c = 0; c < N; c++) {
+        int top = N;
+        k->Y[c] = 0.0; k->flag[c] = c; k->Lnz[c] = 0;
+        for (int p = k->Kp[c]; p < k->Kp[c + 1]; p++) {
+            int i = k->Ki[p], len = 0;
+            k->Y[i] += k->Kx[p];
+            for (; k->flag[i] != c; i = k->parent[i]) { k->pattern[len++] = i; k->flag[i] = c; }
+            while (len > 0) k->pattern[--top] = k->pattern[--len];
+        }
+        double d = k->Y[c];
+        k->Y[c] = 0.0;
+        for (; top < N; top++) {
+            int i = k->pattern[top];
+            double yi = k->Y[i];
+            k->Y[i] = 0.0;
+            int p2 = k->Lp[i] + k->Lnz[i];
+            for (int p = k->Lp[i]; p < p2; p++) k->Y[k->Li[p]] -= k->Lx[p] * yi;
+            double lki = yi / k->D[i];
+            d -= lki * yi;
+            k->Li[p2] = c; k->Lx[p2] = lki; k->Lnz[i]++;
+        }
+        if (d == 0.0) return 1;
+        k->D[c] = d;
+    }
+    return 0;
+}
+
+/* sol <- KKT^-1 rhs (both in the original ordering, length n + m) */
+static void kkt_solve(const osqp_work *w, double *v)
+{
+    kkt_ldl *k = w->kkt;
+    const int N = k->N;
+    double *b = k->b;
+    for (int a = 0; a < N; a++) b[a] = v[k->perm[a]];
+    for (int c = 0; c < N; c++) {
+        double bc = b[c];
+        for (int p = k->Lp[c]; p < k->Lp[c + 1]; p++) b[k->Li[p]] -= k->Lx[p] * bc;
+    }
+    for (int c = 0; c < N; c++) b[c] /= k->D[c];
+    for (int c = N - 1; c >= 0; c--) {
+        double s = b[c];
+        for (int p = k->Lp[c]; p < k->Lp[c + 1]; p++) s -= k->Lx[p] * b[k->Li[p]];
+        b[c] = s;
+    }
+    for (int a = 0; a < N; a++) v[k->perm[a]] = b[a];
+}
+
 /* ---------------------------------------------------------------- setup / update */
 osqp_work *osqp_setup(int n, int m, const double *P, const double *A, const double *q,
                       const double *l, const double *u, const osqp_settings *s)
@@ -293,8 +505,13 @@ osqp_work *osqp_setup(int n, int m, const double *P, const double *A, const doub
     w->constr_type = (int *)calloc((size_t)m + 1, sizeof(int));
     for (int i = 0; i < m; i++) w->constr_type[i] = classify(w, i);
     apply_rho(w);
-    w->L = dalloc(n * n);
-    if (factor(w)) { osqp_cleanup(w); return NULL; }
+    if (w->s.linsys == 1) {
+        if (kkt_setup(w)) { osqp_cleanup(w); return NULL; }
+        w->kkt_rhs = dalloc(n + m);
+    } else {
+        w->L = dalloc(n * n);
+        if (factor(w)) { osqp_cleanup(w); return NULL; }
+    }
     w->x = dalloc(n); w->z = dalloc(m); w->y = dalloc(m);
     w->x_prev = dalloc(n); w->z_prev = dalloc(m);
     w->xt = dalloc(n); w->zt = dalloc(m);
@@ -315,6 +532,7 @@ void osqp_cleanup(osqp_work *w)
     free(w->x); free(w->z); free(w->y); free(w->x_prev); free(w->z_prev); free(w->xt); free(w->zt);
     free(w->delta_x); free(w->delta_y); free(w->Ax); free(w->Px); free(w->Aty); free(w->wn);
     free(w->wm); free(w->sol_x); free(w->sol_y);
+    kkt_free(w->kkt); free(w->kkt_rhs);
     free(w);
 }
 
@@ -504,11 +722,20 @@ int osqp_solve(osqp_work *w)
         memcpy(w->x_prev, w->x, sizeof(double) * n);
         memcpy(w->z_prev, w->z, sizeof(double) * m);
         /* xt, zt */
-        for (int i = 0; i < m; i++) w->wm[i] = w->rho_vec[i] * w->z_prev[i] - w->y[i];
-        csr_mv(&w->At, w->wm, w->xt);
-        for (int j = 0; j < n; j++) w->xt[j] += sigma * w->x_prev[j] - w->q[j];
-        chol_solve(w, w->xt);
-        csr_mv(&w->A, w->xt, w->zt);
+        if (w->kkt) {
+            double *r = w->kkt_rhs;
+            for (int j = 0; j < n; j++) r[j] = sigma * w->x_prev[j] - w->q[j];
+            for (int i = 0; i < m; i++) r[n + i] = w->z_prev[i] - w->rho_inv_vec[i] * w->y[i];
+            kkt_solve(w, r);
+            memcpy(w->xt, r, sizeof(double) * n);
+            for (int i = 0; i < m; i++) w->zt[i] = w->z_prev[i] + w->rho_inv_vec[i] * (r[n + i] - w->y[i]);
+        } else {
+            for (int i = 0; i < m; i++) w->wm[i] = w->rho_vec[i] * w->z_prev[i] - w->y[i];
+            csr_mv(&w->At, w->wm, w->xt);
+            for (int j = 0; j < n; j++) w->xt[j] += sigma * w->x_prev[j] - w->q[j];
+            chol_solve(w, w->xt);
+            csr_mv(&w->A, w->xt, w->zt);
+        }
         /* x */
         for (int j = 0; j < n; j++) {
             w->x[j] = alpha * w->xt[j] + (1.0 - alpha) * w->x_prev[j];

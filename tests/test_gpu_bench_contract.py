@@ -18,28 +18,67 @@ def _last_json(out):
 
 
 def test_bench_line_single_rank():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+    """The default run: the configuration the headline target is quoted on (6-DOF, N = 50, 262144
+    instances), with the roofline of the executed matrix-core work, the CPU baseline and the
+    parity figures against the restated OSQP-default path at the same eps."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, cwd=ROOT)
     d = _last_json(r.stdout.decode())
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert d["config"]["workload"] == "mpc_6dof_B4096_N20" and "model" not in d["config"]
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "mpc_6dof_B262144_N50" and "model" not in d["config"]
+    assert d["config"]["horizon_N"] == 50 and d["config"]["instances_total"] == 262144 and d["config"]["check_fine"] == 0
+    assert d["scaling"] == "strong" and d["timed_s"] >= 0.5 and d["timed_steps"] % 5 == 0
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    assert 0 < rf["frac"] < 1 and d["solved_frac"] == 1.0 and d["value"] > 1e6
+    # frac counts the matrix-core flops actually executed: MFMAs per tile-iteration x 2048 / 16 per instance-iteration
+    per_it = sum(rf["mfma_per_tile_iteration"]) * 2048 / 16
+    assert abs(rf["executed_flops_per_launch"] - per_it * d["iters_mean"] * 262144) < 1e-6 * rf["executed_flops_per_launch"]
+    assert 0 < rf["frac"] < 1 and rf["dense_equivalent_tflops"] > rf["achieved"] and d["solved_frac"] == 1.0
+    assert d["value"] > 1e6
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and cb["unit"] == "solves/s"
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "solves/s"
+    assert cb["single_core"]["value"] > 0 and "LDL" in cb["sample"]
+    par = d["parity"]
+    assert par["solved_by_both"] >= 0.9 * par["instances"] and par["instances"] >= 256
+    # both sides stopped at eps 1e-3; the engine's iterates are the ones nearer the optimum
+    # (max over 2048 trajectories of 456 entries each, N = 50: the far end of the horizon is loosely determined)
+    assert par["gpu_vs_optimum_maxabs"] < 2.5 and par["gpu_vs_optimum_maxabs"] <= par["osqp_defaults_vs_optimum_maxabs"]
+    assert par["gpu_vs_osqp_defaults_maxabs"] <= par["gpu_vs_optimum_maxabs"] + par["osqp_defaults_vs_optimum_maxabs"] + 1e-12
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` without a launcher starts its two ranks itself (gloo rehearsal,
+    both on GPU 0) and prints one line for the two of them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "10",
+                        "--warmup", "2", "--workload", "mpc_6dof_B4096_N20"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    d = _last_json(r.stdout.decode())
+    assert r.returncode == 0 and d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["config"]["instances_total"] == 2 * 4096 and d["solved_frac"] == 1.0
 
 
 def test_bench_two_ranks_shard_the_instances():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10",
-           "--warmup", "2", "--backend", "gloo"]
+           "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
+           "--warmup", "1", "--backend", "gloo", "--workload", "mpc_6dof_B32768_N50"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
     d = _last_json(r.stdout.decode())
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
-    # both ranks' slabs are counted: 2 x 4096 instances per step
-    assert abs(d["value"] - 2 * 4096 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
-    assert sum(d["iters_hist"].values()) == 4096 and d["solved_frac"] == 1.0
+    # both ranks' slabs are counted: 2 x 32768 instances per step
+    assert abs(d["value"] - 2 * 32768 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert sum(d["iters_hist_rank0"].values()) == 32768 and d["solved_frac"] == 1.0
+
+
+def test_bench_fixed_total_is_shared_out():
+    """The default workload keeps 262144 instances in total: two ranks own 131072 each."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--backend", "gloo"]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+    d = _last_json(r.stdout.decode())
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["config"]["instances_total"] == 262144 and d["config"]["instances_rank0"] == 131072

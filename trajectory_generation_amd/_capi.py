@@ -74,12 +74,18 @@ SYMBOLS = {
     "tg_mpc12_get": (_i, [_vp, _i, _i, _dp]),
     "tg_mpc12_rho": (_d, [_vp, _i]),
     "tg_mpc12_kernel_info": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(_i)]),
-    "tg_mpc6_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _vp]),
-    "tg_mpc12_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _vp]),
+    "tg_mpc6_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _ip, _vp]),
+    "tg_mpc12_plant_step": (_i, [_vp, _i, _i, _dp, _dp, _ip, _vp]),
+    "tg_mpc6_get_opts": (_i, [_vp, C.POINTER(SolverOpts)]),
+    "tg_mpc6_set_opts": (_i, [_vp, C.POINTER(SolverOpts)]),
+    "tg_mpc6_last_residuals": (_i, [_vp, _i, _dp, _dp]),
+    "tg_mpc12_get_opts": (_i, [_vp, _i, C.POINTER(SolverOpts)]),
+    "tg_mpc12_set_opts": (_i, [_vp, C.POINTER(SolverOpts)]),
+    "tg_mpc12_last_residuals": (_i, [_vp, _i, _i, _dp, _dp]),
     "tg_ref_shift": (_i, [_i, _i, _i, _i, _dp, _vp]),
     "tg_copy_to_host": (_i, [_vp, _vp, C.c_ulonglong]),
     "tg_timing_enable": (None, [_i]),
-    "tg_timing_read": (_i, [C.POINTER(_d), C.POINTER(_i), C.POINTER(_d), _i]),
+    "tg_timing_read": (_i, [C.POINTER(_d), C.POINTER(_i), _i]),
 }
 
 _lib = None

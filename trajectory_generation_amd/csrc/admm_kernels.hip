@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "device_types.h"
@@ -1085,7 +1086,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (g == 0) {
                     if (a.status) a.status[inst] = conv ? TG_DEV_SOLVED : (pinf ? TG_DEV_PRIMAL_INFEASIBLE : TG_DEV_MAX_ITER);
                     if (a.iters) a.iters[inst] = local;
-                    if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.ld + inst] = m_rd; }
+                    if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.res_ld + inst] = m_rd; }
                 }
                 if (a.warm_out) {
 #pragma unroll
@@ -1259,13 +1260,27 @@ struct PlantDev {
     double A[12 * 12], Bm[12 * 4];   // row-major, model-level (12-state: block diagonal)
 };
 
-__global__ __launch_bounds__(256) void plant_step_kernel(const PlantDev P, int B, int ld,
+// An instance whose last solve did not reach "solved" in every stage received no new plan (the
+// reference publishes nothing then, mpc_ros.cpp:428-432): it keeps following the last plan it got,
+// i.e. its U moves one step up (the last step becomes zero: beyond the plan's end it coasts) and the
+// new first control is applied.  status: [nstat][ld] or null (every instance counts as solved).
+__global__ __launch_bounds__(256) void plant_step_kernel(const PlantDev P, int B, int ld, int N,
                                                           double *__restrict__ x0,
-                                                          const double *__restrict__ U)
+                                                          double *__restrict__ U,
+                                                          const int *__restrict__ status, int nstat)
 {
 #pragma clang fp contract(off)
     const int inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= B) return;
+    bool ok = true;
+    if (status)
+        for (int k = 0; k < nstat; k++) ok = ok && status[(size_t)k * ld + inst] == TG_DEV_SOLVED;
+    if (!ok) {
+        for (int i = 0; i + 1 < N; i++)
+            for (int k = 0; k < P.nu; k++)
+                U[(size_t)(i * P.nu + k) * ld + inst] = U[(size_t)((i + 1) * P.nu + k) * ld + inst];
+        for (int k = 0; k < P.nu; k++) U[(size_t)((N - 1) * P.nu + k) * ld + inst] = 0.0;
+    }
     double x[12], u[4], y[12];
     for (int c = 0; c < P.nx; c++) x[c] = x0[(size_t)c * ld + inst];
     for (int k = 0; k < P.nu; k++) u[k] = U[(size_t)k * ld + inst];
@@ -1312,6 +1327,9 @@ static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream
     auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR>;
     const size_t lds_bytes = admm_lds_bytes(P);
     // the dynamic LDS limit of a kernel is per device and sticky: raise it when it has to grow
+    // (per-variant caches, shared by every handle and host thread of the process)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     static int lds_set[64] = {0};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -1454,14 +1472,14 @@ hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double 
     return hipGetLastError();
 }
 
-hipError_t launch_plant_step(int nx, int nu, const double *A, const double *Bm, int B, int ld, double *x0,
-                             const double *U, hipStream_t s)
+hipError_t launch_plant_step(int nx, int nu, int N, const double *A, const double *Bm, int B, int ld, double *x0,
+                             double *U, const int *status, int nstat, hipStream_t s)
 {
     PlantDev P{};
     P.nx = nx; P.nu = nu;
     for (int i = 0; i < nx * nx; i++) P.A[i] = A[i];
     for (int i = 0; i < nx * nu; i++) P.Bm[i] = Bm[i];
-    hipLaunchKernelGGL(plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, s, P, B, ld, x0, U);
+    hipLaunchKernelGGL(plant_step_kernel, dim3((B + 255) / 256), dim3(256), 0, s, P, B, ld, N, x0, U, status, nstat);
     return hipGetLastError();
 }
 

@@ -72,7 +72,8 @@ struct BatchArgs {
     double *X, *U;
     int *status, *iters;
     const int *gate;         // optional: status of the upstream stage, instances != solved are skipped
-    double *res;             // optional [2][ld]: primal / dual residual at exit
+    double *res;             // optional [2][res_ld]: primal / dual residual at exit
+    int res_ld;
     int warm_in, warm_out;
     double *warm;            // [warm_rows][ldw] iterates kept between calls
     // Work queue for grids smaller than the batch: *queue counts the instances handed out beyond

@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,8 +19,8 @@ hipError_t launch_assemble(const AsmDev &P, const BatchArgs &a, double *q, doubl
 hipError_t launch_xy_bounds(int B, int ld, int N, double xy_max_vel, double xy_max_accel,
                             double z_max_accel, const double *X, double *xy_max, double *mixed_max,
                             hipStream_t s);
-hipError_t launch_plant_step(int nx, int nu, const double *A, const double *Bm, int B, int ld, double *x0,
-                             const double *U, hipStream_t s);
+hipError_t launch_plant_step(int nx, int nu, int N, const double *A, const double *Bm, int B, int ld, double *x0,
+                             double *U, const int *status, int nstat, hipStream_t s);
 hipError_t launch_ref_shift(int B, int ld, int nx, int N, double *ref, hipStream_t s);
 hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
                           hipStream_t s);
@@ -38,22 +39,29 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
     } while (0)
 
 // ---------------------------------------------------------------- kernel timing
+// Process-wide totals over every handle and device; g_time_mu guards them, so solves issued from
+// several host threads may be timed together.  Events remember the device they were created on.
+static std::mutex g_time_mu;
 static bool g_timing = false;
-static double g_admm_ms = 0.0, g_iters_total = 0.0;
+static double g_admm_ms = 0.0;
 static int g_admm_launches = 0;
-struct PendingEvent { hipEvent_t a, b; };
+struct PendingEvent { hipEvent_t a, b; int dev; };
 static std::vector<PendingEvent> g_pending;
 
-static void drain_events()
+static void drain_events()   // caller holds g_time_mu
 {
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;
     for (auto &p : g_pending) {
         float ms = 0.f;
+        hipSetDevice(p.dev);
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             g_admm_ms += ms; g_admm_launches++;
         }
         hipEventDestroy(p.a); hipEventDestroy(p.b);
     }
     g_pending.clear();
+    if (have_cur) hipSetDevice(cur);
 }
 
 // ---------------------------------------------------------------- device residency of one stage
@@ -78,6 +86,7 @@ struct DevStage {
     int32_t *d_qrr = nullptr, *d_x0r = nullptr, *d_ovb = nullptr, *d_ovm = nullptr;
     // warm-start iterates of the instance slots
     double *d_warm = nullptr; int warm_cap = 0; bool warm_valid = false; int warm_B = 0;
+    double *d_res = nullptr; int res_cap = 0, res_B = 0;
 
     int init(const StageModel &mdl, const tg_solver_opts &o, double rho)
     {
@@ -200,7 +209,7 @@ struct DevStage {
     {
         hipFree(d_Mfrag); hipFree(d_DUfrag); hipFree(d_queue);
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
-        hipFree(d_ovm); hipFree(d_warm);
+        hipFree(d_ovm); hipFree(d_warm); hipFree(d_res);
     }
     void kernel_info(int *mfma, int *lowrank) const
     {
@@ -214,7 +223,10 @@ struct DevStage {
     {
         return (size_t)3 * sp.n_int + (size_t)2 * sp.nax * (sp.mdl.N + 1) * sp.D + (size_t)12 * (sp.mdl.N + 1);
     }
-    int ensure_warm(int B)
+    // The kernel writes a slot's warm rows only when the slot's instance ran (a gated instance, or
+    // one beyond a smaller batch, leaves them alone), so a fresh array starts as all zeros: zero
+    // iterates are a cold start.
+    int ensure_warm(int B, hipStream_t s)
     {
         int cap = (B + 15) / 16 * 16;
         if (cap <= warm_cap) return TG_OK;
@@ -222,32 +234,101 @@ struct DevStage {
         size_t rows = warm_rows();
         HIP_TRY(hipMalloc((void **)&d_warm, rows * cap * sizeof(double)));
         warm_cap = cap;
+        HIP_TRY(hipMemsetAsync(d_warm, 0, rows * cap * sizeof(double), s));
         return TG_OK;
     }
-    // one batched ADMM solve of this stage
-    int solve(BatchArgs a, int warm, hipStream_t s)
+    // primal / dual residual of every instance at its exit, [2][res_cap]
+    int ensure_res(int ld)
+    {
+        if (ld <= res_cap) return TG_OK;
+        hipFree(d_res); d_res = nullptr; res_cap = 0; res_B = 0;
+        HIP_TRY(hipMalloc((void **)&d_res, (size_t)2 * ld * sizeof(double)));
+        res_cap = ld;
+        return TG_OK;
+    }
+    // One batched ADMM solve of this stage.  no_alloc: the caller guarantees that nothing here may
+    // allocate (no warm start, no residual record, no timing events; a.queue_mem is the caller's).
+    int solve(BatchArgs a, int warm, hipStream_t s, bool no_alloc = false)
     {
         a.warm_in = 0; a.warm_out = 0; a.ldw = 0;
         a.warm = nullptr;
         if (warm) {
-            int rc = ensure_warm(a.B);
+            if (no_alloc) return fail(TG_E_ARG, "warm start is not available without allocation");
+            int rc = ensure_warm(a.B, s);
             if (rc) return rc;
             a.ldw = warm_cap;
             a.warm = d_warm;
             a.warm_in = (warm_valid && warm_B >= a.B) ? 1 : 0;
             a.warm_out = 1;
         }
-        a.queue_mem = grid_cap >= 0 ? d_queue : nullptr;
+        a.res = nullptr; a.res_ld = 0;
+        if (!no_alloc) {
+            int rc = ensure_res(a.ld);
+            if (rc) return rc;
+            a.res = d_res; a.res_ld = res_cap;
+            a.queue_mem = grid_cap >= 0 ? d_queue : nullptr;
+        }
         a.grid_cap = grid_cap;
         const char *why = "";
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_timing) { HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventRecord(e0, s)); }
+        bool timing = false;
+        if (!no_alloc) {
+            std::lock_guard<std::mutex> lk(g_time_mu);
+            timing = g_timing;
+        }
+        if (timing) {
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, s) != hipSuccess) {
+                if (e0) hipEventDestroy(e0);
+                if (e1) hipEventDestroy(e1);
+                return fail(TG_E_HIP, "timing events could not be created");
+            }
+        }
         hipError_t e = launch_admm(dev, a, s, &why);
-        if (e != hipSuccess) return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
-                                         std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
-        if (g_timing) { HIP_TRY(hipEventRecord(e1, s)); g_pending.push_back({e0, e1}); }
+        if (e != hipSuccess) {
+            if (timing) { hipEventDestroy(e0); hipEventDestroy(e1); }
+            return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
+                        std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
+        }
+        if (timing) {
+            if (hipEventRecord(e1, s) != hipSuccess) {
+                hipEventDestroy(e0); hipEventDestroy(e1);
+                return fail(TG_E_HIP, "timing event could not be recorded");
+            }
+            int d = 0;
+            hipGetDevice(&d);
+            std::lock_guard<std::mutex> lk(g_time_mu);
+            g_pending.push_back({e0, e1, d});
+        }
         if (warm) { warm_valid = true; warm_B = a.B; }
+        if (!no_alloc) res_B = a.B;
         return TG_OK;
+    }
+    // residuals of the last solve, host arrays of B doubles each (either may be null)
+    int residuals(int B, double *prim, double *dual) const
+    {
+        if (B < 0 || B > res_B) return fail(TG_E_STATE, "no residuals recorded for that many instances");
+        if (B == 0) return TG_OK;
+        HIP_TRY(hipDeviceSynchronize());
+        if (prim) HIP_TRY(hipMemcpy(prim, d_res, sizeof(double) * B, hipMemcpyDeviceToHost));
+        if (dual) HIP_TRY(hipMemcpy(dual, d_res + res_cap, sizeof(double) * B, hipMemcpyDeviceToHost));
+        return TG_OK;
+    }
+    // effective options: automatic choices resolved
+    void effective_opts(const tg_solver_opts &asked, tg_solver_opts *out) const
+    {
+        *out = asked;
+        out->rho = sp.rho; out->sigma = dev.sigma; out->alpha = dev.alpha;
+        out->eps_abs = dev.eps_abs; out->eps_rel = dev.eps_rel; out->eps_prim_inf = dev.eps_prim_inf;
+        out->max_iter = dev.max_iter; out->check_termination = dev.check; out->check_fine = dev.check_fine;
+        out->grid_cap = grid_cap; out->lowrank = dev.lr;
+        for (int k = 0; k < 4; k++) out->rho_scale[k] = sp.rho_scale[k];
+    }
+    // options that do not enter the factorised operator can change on a live handle
+    void set_run_opts(const tg_solver_opts &o)
+    {
+        dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
+        dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
+        grid_cap = o.grid_cap;
     }
     int get(int which, double *out) const
     {
@@ -330,14 +411,18 @@ int tg_copy_to_host(void *dst, const void *d_src, unsigned long long bytes)
     return TG_OK;
 }
 
-void tg_timing_enable(int on) { g_timing = on != 0; }
-int tg_timing_read(double *ms, int *launches, double *iters_total, int reset)
+void tg_timing_enable(int on)
 {
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    g_timing = on != 0;
+}
+int tg_timing_read(double *ms, int *launches, int reset)
+{
+    std::lock_guard<std::mutex> lk(g_time_mu);
     drain_events();
     if (ms) *ms = g_admm_ms;
     if (launches) *launches = g_admm_launches;
-    if (iters_total) *iters_total = g_iters_total;
-    if (reset) { g_admm_ms = 0; g_admm_launches = 0; g_iters_total = 0; }
+    if (reset) { g_admm_ms = 0; g_admm_launches = 0; }
     return TG_OK;
 }
 
@@ -388,7 +473,7 @@ int tg_mpc6_solve_batch(tg_mpc6 *h, int B, int ld, const double *d_x0, const dou
     BatchArgs a{};
     a.B = B; a.ld = ld; a.ref_ld = ld; a.ov_ld = 0;
     a.x0 = d_x0; a.ref = d_ref; a.ov_box = nullptr; a.ov_mixed = nullptr;
-    a.X = d_X; a.U = d_U; a.status = d_status; a.iters = d_iters; a.res = nullptr;
+    a.X = d_X; a.U = d_U; a.status = d_status; a.iters = d_iters;
     return h->st.solve(a, warm, (hipStream_t)stream);
 }
 
@@ -410,6 +495,9 @@ int tg_mpc6_solve_host(tg_mpc6 *h, int B, const double *x0, const double *ref, d
     HIP_TRY(hipMemcpy(dx0, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     to_soa(ref, B, rr, ld, tmp);
     HIP_TRY(hipMemcpy(dref, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    // an instance that does not reach "solved" gets no X / U from the kernel: zeros, not what an
+    // earlier call left in the staging buffer
+    HIP_TRY(hipMemset(dX, 0, (size_t)(rX + rU) * ld * sizeof(double)));
     rc = tg_mpc6_solve_batch(h, B, ld, dx0, dref, dX, dU, h->hs.di, h->hs.di + ld, warm, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
@@ -471,14 +559,14 @@ int tg_mpc6_assemble_host(tg_mpc6 *h, int B, const double *x0, const double *ref
     return TG_OK;
 }
 
-int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, const double *d_U, void *stream)
+int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, double *d_U, const int *d_status, void *stream)
 {
     if (!h) return fail(TG_E_ARG, "null handle");
     if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
     if (B == 0) return TG_OK;
     if (!d_x0 || !d_U) return fail(TG_E_ARG, "null device array");
     HIP_TRY(hipSetDevice(h->device));
-    HIP_TRY(launch_plant_step(6, 3, h->st.sp.mdl.Ad, h->st.sp.mdl.Bd, B, ld, d_x0, d_U, (hipStream_t)stream));
+    HIP_TRY(launch_plant_step(6, 3, h->p.N, h->st.sp.mdl.Ad, h->st.sp.mdl.Bd, B, ld, d_x0, d_U, d_status, 1, (hipStream_t)stream));
     return TG_OK;
 }
 
@@ -511,8 +599,51 @@ int tg_mpc6_kernel_info(const tg_mpc6 *h, int *mfma, int *lowrank)
     h->st.kernel_info(mfma, lowrank);
     return TG_OK;
 }
+int tg_mpc6_get_opts(const tg_mpc6 *h, tg_solver_opts *out)
+{
+    if (!h || !out) return fail(TG_E_ARG, "null argument");
+    h->st.effective_opts(h->o, out);
+    return TG_OK;
+}
+// true when `o` asks for the factorised operator the handle already has
+static bool same_operator(const tg_solver_opts &have, const tg_solver_opts &o)
+{
+    bool same = (o.rho <= 0 || o.rho == have.rho) && o.sigma == have.sigma;
+    for (int k = 0; k < 4; k++) same = same && (o.rho_scale[k] <= 0 || o.rho_scale[k] == have.rho_scale[k]);
+    return same;
+}
+int tg_mpc6_set_opts(tg_mpc6 *h, const tg_solver_opts *o)
+{
+    if (!h || !o) return fail(TG_E_ARG, "null argument");
+    int rc = check_opts(*o);
+    if (rc) return rc;
+    tg_solver_opts have;
+    h->st.effective_opts(h->o, &have);
+    if (!same_operator(have, *o)) return fail(TG_E_STATE, "rho, sigma and rho_scale are frozen at create: make a new handle");
+    h->st.set_run_opts(*o);
+    h->o.alpha = o->alpha; h->o.eps_abs = o->eps_abs; h->o.eps_rel = o->eps_rel; h->o.eps_prim_inf = o->eps_prim_inf;
+    h->o.max_iter = o->max_iter; h->o.check_termination = o->check_termination; h->o.check_fine = o->check_fine;
+    h->o.grid_cap = o->grid_cap;
+    return TG_OK;
+}
+int tg_mpc6_last_residuals(tg_mpc6 *h, int B, double *prim, double *dual)
+{
+    if (!h) return fail(TG_E_ARG, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return h->st.residuals(B, prim, dual);
+}
 
 // ================================================================ 12-state
+// Where a 12-state solve keeps what passes between its stages: the handle's own hipMalloc'ed
+// arrays (ensure_inter) or, for the entry point that may not allocate, a carve-up of the device's
+// static scratch array.
+struct InterView {
+    double *xy_max = nullptr, *mixed_max = nullptr, *yaw_ref = nullptr;
+    int ld = 0;
+    int *queue[3] = {nullptr, nullptr, nullptr};   // per stage slot (z, xy, yaw); null: the stage's own counter
+    bool no_alloc = false;
+};
+
 struct tg_mpc12 {
     tg_mpc12_params p; tg_solver_opts o; int device;
     DevStage st[4]; // indexed by TG_FAM_*; [0] unused
@@ -532,7 +663,15 @@ struct tg_mpc12 {
     double *xy_max() { return d_inter; }
     double *mixed_max() { return d_inter + (size_t)6 * p.N * inter_ld; }
     double *yaw_ref() { return d_inter + (size_t)12 * p.N * inter_ld; }
+    InterView view();
 };
+
+InterView tg_mpc12::view()
+{
+    InterView iv;
+    iv.xy_max = xy_max(); iv.mixed_max = mixed_max(); iv.yaw_ref = yaw_ref(); iv.ld = inter_ld;
+    return iv;
+}
 
 int tg_mpc12_create(const tg_mpc12_params *p, const tg_solver_opts *o, const double *rho_xyz,
                     int device, tg_mpc12 **out)
@@ -574,16 +713,15 @@ void tg_mpc12_destroy(tg_mpc12 *h)
 
 // gated: instances whose upstream stage did not solve are skipped (status TG_UNSOLVED), as
 // MPC12STATE::mpcLoop returns at the first failing stage (mpc_12state.cpp:1374-1453)
-static int mpc12_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0, const double *d_ref,
+static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int ld, const double *d_x0, const double *d_ref,
                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s,
                        bool gated = false)
 {
-    int rc = h->ensure_inter(ld);
-    if (rc) return rc;
     const tg_mpc12_params &p = h->p;
+    if (iv.ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
     BatchArgs a{};
-    a.B = B; a.ld = ld; a.ref_ld = ld; a.ov_ld = h->inter_ld;
-    a.x0 = d_x0; a.ref = d_ref; a.X = d_X; a.U = d_U; a.res = nullptr;
+    a.B = B; a.ld = ld; a.ref_ld = ld; a.ov_ld = iv.ld;
+    a.x0 = d_x0; a.ref = d_ref; a.X = d_X; a.U = d_U;
     const int slot = stage == TG_FAM_Z ? 0 : stage == TG_FAM_XY ? 1 : 2;
     a.status = d_status ? d_status + (size_t)slot * ld : nullptr;
     a.iters = d_iters ? d_iters + (size_t)slot * ld : nullptr;
@@ -591,16 +729,14 @@ static int mpc12_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0
     if (stage == TG_FAM_XY) {
         // computeXYBounds from the Z solution already in X, then updateXYQP + solve
         HIP_TRY(launch_xy_bounds(B, ld, p.N, p.xy_max_vel, p.xy_max_accel, p.z_max_accel, d_X,
-                                 h->xy_max(), h->mixed_max(), s));
-        // the bound arrays use the handle's leading dimension
-        if (h->inter_ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
-        a.ov_box = h->xy_max(); a.ov_mixed = h->mixed_max();
+                                 iv.xy_max, iv.mixed_max, s));
+        a.ov_box = iv.xy_max; a.ov_mixed = iv.mixed_max;
     } else if (stage == TG_FAM_YAW) {
-        if (h->inter_ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
-        HIP_TRY(launch_yaw_ref(B, ld, p.N, d_ref, d_X, h->yaw_ref(), s));
-        a.ref = h->yaw_ref(); a.ref_ld = h->inter_ld;
+        HIP_TRY(launch_yaw_ref(B, ld, p.N, d_ref, d_X, iv.yaw_ref, s));
+        a.ref = iv.yaw_ref; a.ref_ld = iv.ld;
     }
-    return h->st[stage].solve(a, warm, s);
+    if (iv.no_alloc) a.queue_mem = h->st[stage].grid_cap >= 0 ? iv.queue[slot] : nullptr;
+    return h->st[stage].solve(a, warm, s, iv.no_alloc);
 }
 
 static int mpc12_check(tg_mpc12 *h, int B, int ld, const void *a, const void *b, const void *c, const void *d)
@@ -620,13 +756,12 @@ int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const d
     // keep one leading dimension for the intermediates of a handle
     if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
     hipStream_t s = (hipStream_t)stream;
-    if (!d_status) {
-        if ((rc = h->ensure_inter(ld))) return rc;
-        d_status = h->own_status();
-    }
-    if ((rc = mpc12_stage(h, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
-    if ((rc = mpc12_stage(h, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
-    if ((rc = mpc12_stage(h, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = h->ensure_inter(ld))) return rc;
+    if (!d_status) d_status = h->own_status();
+    const InterView iv = h->view();
+    if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
     return TG_OK;
 }
 
@@ -638,7 +773,8 @@ int tg_mpc12_solve_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_
     if (stage < TG_FAM_XY || stage > TG_FAM_YAW) return fail(TG_E_ARG, "stage must be XY, Z or YAW");
     HIP_TRY(hipSetDevice(h->device));
     if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
-    return mpc12_stage(h, stage, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, (hipStream_t)stream);
+    if ((rc = h->ensure_inter(ld))) return rc;
+    return mpc12_stage(h, h->view(), stage, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, (hipStream_t)stream);
 }
 
 int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref, double *X, double *U,
@@ -761,7 +897,7 @@ int tg_mpc12_assemble_host(tg_mpc12 *h, int stage, int B, const double *x0, cons
     return TG_OK;
 }
 
-int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, const double *d_U, void *stream)
+int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, double *d_U, const int *d_status, void *stream)
 {
     if (!h) return fail(TG_E_ARG, "null handle");
     if (B < 0 || ld < B) return fail(TG_E_ARG, "need 0 <= B <= ld");
@@ -780,7 +916,7 @@ int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, const double *
         }
         r0 += m.nx; u0 += m.nu;
     }
-    HIP_TRY(launch_plant_step(12, 4, A, Bm, B, ld, d_x0, d_U, (hipStream_t)stream));
+    HIP_TRY(launch_plant_step(12, 4, h->p.N, A, Bm, B, ld, d_x0, d_U, d_status, 3, (hipStream_t)stream));
     return TG_OK;
 }
 
@@ -808,6 +944,36 @@ int tg_mpc12_kernel_info(const tg_mpc12 *h, int stage, int *mfma, int *lowrank)
     if (!h || stage < 1 || stage > 3) return fail(TG_E_ARG, "bad argument");
     h->st[stage].kernel_info(mfma, lowrank);
     return TG_OK;
+}
+int tg_mpc12_get_opts(const tg_mpc12 *h, int stage, tg_solver_opts *out)
+{
+    if (!h || !out || stage < 1 || stage > 3) return fail(TG_E_ARG, "bad argument");
+    h->st[stage].effective_opts(h->o, out);
+    return TG_OK;
+}
+int tg_mpc12_set_opts(tg_mpc12 *h, const tg_solver_opts *o)
+{
+    if (!h || !o) return fail(TG_E_ARG, "null argument");
+    int rc = check_opts(*o);
+    if (rc) return rc;
+    for (int f = 1; f <= 3; f++) {
+        tg_solver_opts have;
+        h->st[f].effective_opts(h->o, &have);
+        tg_solver_opts want = *o;
+        want.rho = 0.0;     // the per-stage rho came from rho_xyz or the built-in choice
+        if (!same_operator(have, want)) return fail(TG_E_STATE, "sigma and rho_scale are frozen at create: make a new handle");
+    }
+    for (int f = 1; f <= 3; f++) h->st[f].set_run_opts(*o);
+    h->o.alpha = o->alpha; h->o.eps_abs = o->eps_abs; h->o.eps_rel = o->eps_rel; h->o.eps_prim_inf = o->eps_prim_inf;
+    h->o.max_iter = o->max_iter; h->o.check_termination = o->check_termination; h->o.check_fine = o->check_fine;
+    h->o.grid_cap = o->grid_cap;
+    return TG_OK;
+}
+int tg_mpc12_last_residuals(tg_mpc12 *h, int stage, int B, double *prim, double *dual)
+{
+    if (!h || stage < 1 || stage > 3) return fail(TG_E_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    return h->st[stage].residuals(B, prim, dual);
 }
 
 } // extern "C"

@@ -184,11 +184,27 @@ class BatchedMPC6:
 
     NX, NU = 6, 3
 
-    def plant_step(self, buf, stream=None, B=None):
-        """x0 <- A x0 + B u(0) with the U of the last solve (test_mpc_6dof.cpp:115-122)."""
+    def plant_step(self, buf, stream=None, B=None, gated=True):
+        """x0 <- A x0 + B u(0) with the U of the last solve (test_mpc_6dof.cpp:115-122).  gated:
+        an instance whose solve failed keeps following the last plan it received (its U moves one
+        step up); ungated, row 0 of U is applied whatever the status."""
         B = buf["B"] if B is None else B
         capi.check(self.lib.tg_mpc6_plant_step(self._h, B, buf["ld"], _ptr(buf["x0"]), _ptr(buf["U"]),
-                                               _stream_ptr(stream)))
+                                               _ptr(buf["status"]) if gated else None, _stream_ptr(stream)))
+
+    def get_opts(self):
+        o = capi.SolverOpts()
+        capi.check(self.lib.tg_mpc6_get_opts(self._h, C.byref(o)))
+        return o
+
+    def set_opts(self, opts):
+        capi.check(self.lib.tg_mpc6_set_opts(self._h, C.byref(opts)))
+
+    def last_residuals(self, B):
+        """(primal, dual) residual of instances [0, B) at the check that ended the last solve."""
+        pr, du = np.zeros(B), np.zeros(B)
+        capi.check(self.lib.tg_mpc6_last_residuals(self._h, B, pr.ctypes.data_as(C.c_void_p), du.ctypes.data_as(C.c_void_p)))
+        return pr, du
 
     def ref_shift(self, buf, stream=None, B=None):
         B = buf["B"] if B is None else B
@@ -323,12 +339,26 @@ class BatchedMPC12:
 
     NX, NU = 12, 4
 
-    def plant_step(self, buf, stream=None, B=None):
+    def plant_step(self, buf, stream=None, B=None, gated=True):
         """x0 <- A x0 + B u(0), A / B = getTransitionMatrix / getInputMatrix
-        (test_mpc_12state.cpp:193-197, mpc_12state.cpp:2001-2025)."""
+        (test_mpc_12state.cpp:193-197, mpc_12state.cpp:2001-2025); gated as for the 6-DOF engine."""
         B = buf["B"] if B is None else B
         capi.check(self.lib.tg_mpc12_plant_step(self._h, B, buf["ld"], _ptr(buf["x0"]), _ptr(buf["U"]),
-                                                _stream_ptr(stream)))
+                                                _ptr(buf["status"]) if gated else None, _stream_ptr(stream)))
+
+    def get_opts(self, stage):
+        o = capi.SolverOpts()
+        capi.check(self.lib.tg_mpc12_get_opts(self._h, self.STAGES[stage], C.byref(o)))
+        return o
+
+    def set_opts(self, opts):
+        capi.check(self.lib.tg_mpc12_set_opts(self._h, C.byref(opts)))
+
+    def last_residuals(self, stage, B):
+        pr, du = np.zeros(B), np.zeros(B)
+        capi.check(self.lib.tg_mpc12_last_residuals(self._h, self.STAGES[stage], B, pr.ctypes.data_as(C.c_void_p),
+                                                    du.ctypes.data_as(C.c_void_p)))
+        return pr, du
 
     def ref_shift(self, buf, stream=None, B=None):
         B = buf["B"] if B is None else B
@@ -340,6 +370,6 @@ def timing_enable(on=True):
 
 
 def timing_read(reset=True):
-    ms, n, it = C.c_double(), C.c_int(), C.c_double()
-    capi.load().tg_timing_read(C.byref(ms), C.byref(n), C.byref(it), int(reset))
+    ms, n = C.c_double(), C.c_int()
+    capi.load().tg_timing_read(C.byref(ms), C.byref(n), int(reset))
     return ms.value, n.value
