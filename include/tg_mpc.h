@@ -192,6 +192,22 @@ int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const d
 int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref, double *X,
                         double *U, int *status, int *iters, int warm);
 
+/* No counterpart in the reference: tg_mpc12_solve_batch for callers that cannot allocate device
+ * memory at call time -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same three stages, same kernels and bit-identical X / U / status / iters (cold start
+ * only: there is no warm argument, no residual record and no kernel timing), but the arrays that
+ * pass between the stages (xy_max, mixed_max, yaw_ref), the stage status rows when d_status is NULL
+ * and the kernels' queue counters live in a static device array of 16 MiB that every GPU the
+ * library runs on holds until the process ends, instead of in buffers the handle allocates.  The
+ * call makes no hipMalloc / hipFree.  Limit: tg_mpc12_static_scratch_bytes(N, ld) = 256 +
+ * roundup(12 ld, 256) + 8 (13 N + 1) ld must not exceed 16 MiB (N = 20: ld <= 7984; N = 50:
+ * ld <= 3216); larger batches are refused with TG_E_ARG.  All calls on one GPU share that GPU's
+ * array: two of them overlapping in time (different streams or threads, any handles) race; calls
+ * on one stream, or on different GPUs, do not.  tg_mpc12_intermediates does not see its arrays. */
+int tg_mpc12_solve_batch_static(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                                double *d_X, double *d_U, int *d_status, int *d_iters, void *stream);
+unsigned long long tg_mpc12_static_scratch_bytes(int N, int ld);
+
 /* single stages with the upstream solution injected, for stage-by-stage checks:
  * stage = TG_FAM_Z / TG_FAM_XY / TG_FAM_YAW.  For XY, X must already hold the z rows
  * (6..8 of every step); for YAW, the xy rows (0..5). */

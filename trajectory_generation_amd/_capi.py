@@ -65,6 +65,8 @@ SYMBOLS = {
     "tg_mpc12_destroy": (None, [_vp]),
     "tg_mpc12_solve_batch": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _i, _vp]),
     "tg_mpc12_solve_host": (_i, [_vp, _i, _dp, _dp, _dp, _dp, _ip, _ip, _i]),
+    "tg_mpc12_solve_batch_static": (_i, [_vp, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _vp]),
+    "tg_mpc12_static_scratch_bytes": (C.c_ulonglong, [_i, _i]),
     "tg_mpc12_solve_stage": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _ip, _ip, _vp]),
     "tg_mpc12_intermediates": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i)]),
     "tg_mpc12_assemble_stage": (_i, [_vp, _i, _i, _i, _dp, _dp, _dp, _dp, _dp, _dp, _vp]),

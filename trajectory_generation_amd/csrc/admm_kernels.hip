@@ -1311,6 +1311,38 @@ __global__ __launch_bounds__(256) void ref_shift_kernel(int B, int ld, int nx, i
     if (N >= 1) ref[(size_t)(N * nx + a) * ld + inst] = cur + (cur - prev);
 }
 
+// ---------------------------------------------------------------- static scratch
+// Device memory of the entry point that may not allocate (tg_mpc12_solve_batch_static): the
+// inter-stage arrays, the stage status rows and the queue counters live in this array instead of
+// in hipMalloc'ed buffers.  Every GPU holds its own copy at its own address; in host code the name
+// `scratch` is only a handle for hipGetSymbolAddress, never a device address: the address is looked
+// up once per device (static_scratch_init, called with that device current) and everything else --
+// kernel arguments, hipMemsetAsync -- uses the looked-up pointer.
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static std::mutex g_scratch_mu;
+static void *g_scratch_ptr[64] = {nullptr};
+
+hipError_t static_scratch_init(int dev)
+{
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev]) return hipSuccess;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    if (!ptr) return hipErrorInvalidSymbol;
+    g_scratch_ptr[dev] = ptr;
+    return hipSuccess;
+}
+
+// the device's copy of the array, or null before static_scratch_init(dev)
+void *static_scratch_ptr(int dev)
+{
+    if (dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    return g_scratch_ptr[dev];
+}
+
 // ---------------------------------------------------------------- host-callable launchers
 size_t admm_lds_bytes(const StageDev &P)
 {

@@ -24,6 +24,8 @@ hipError_t launch_plant_step(int nx, int nu, int N, const double *A, const doubl
 hipError_t launch_ref_shift(int B, int ld, int nx, int N, double *ref, hipStream_t s);
 hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
                           hipStream_t s);
+hipError_t static_scratch_init(int dev);
+void *static_scratch_ptr(int dev);
 } // namespace tg
 
 using namespace tg;
@@ -690,6 +692,8 @@ int tg_mpc12_create(const tg_mpc12_params *p, const tg_solver_opts *o, const dou
     int rc = check_opts(oo);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(device));
+    // address of this device's static scratch array (tg_mpc12_solve_batch_static), looked up once per device
+    HIP_TRY(static_scratch_init(device));
     tg_mpc12 *h = new tg_mpc12();
     h->p = *p; h->o = oo; h->device = device;
     const int fams[3] = {TG_FAM_XY, TG_FAM_Z, TG_FAM_YAW};
@@ -762,6 +766,47 @@ int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const d
     if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
     if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
     if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
+    return TG_OK;
+}
+
+// The same three stages with every piece of device memory beyond the caller's arrays taken from
+// the device's static scratch array: [3 queue counters, 64 B apart | status 3 x ld ints | xy_max 6N x ld |
+// mixed_max 6N x ld | yaw_ref (N+1) x ld doubles].  Nothing here allocates: no hipMalloc / hipFree, no
+// warm start, no residual record, no timing events.
+unsigned long long tg_mpc12_static_scratch_bytes(int N, int ld)
+{
+    if (N < 1 || ld < 1) return 0;
+    const unsigned long long status = ((unsigned long long)3 * ld * sizeof(int) + 255) / 256 * 256;
+    return 256 + status + (unsigned long long)(13 * (unsigned long long)N + 1) * ld * sizeof(double);
+}
+
+int tg_mpc12_solve_batch_static(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
+                                double *d_X, double *d_U, int *d_status, int *d_iters, void *stream)
+{
+    int rc = mpc12_check(h, B, ld, d_x0, d_ref, d_X, d_U);
+    if (rc || B == 0) return rc;
+    const unsigned long long need = tg_mpc12_static_scratch_bytes(h->p.N, ld);
+    if (need > kStaticScratchBytes)
+        return fail(TG_E_ARG, "batch too large for the static scratch: N = " + std::to_string(h->p.N) + ", ld = " +
+                                  std::to_string(ld) + " need " + std::to_string(need) + " bytes of " +
+                                  std::to_string(kStaticScratchBytes) + " (use tg_mpc12_solve_batch, or split the batch)");
+    HIP_TRY(hipSetDevice(h->device));
+    unsigned char *base = (unsigned char *)static_scratch_ptr(h->device);
+    if (!base) return fail(TG_E_STATE, "static scratch of this device was not initialised");
+    InterView iv;
+    iv.no_alloc = true;
+    iv.ld = ld;
+    for (int k = 0; k < 3; k++) iv.queue[k] = (int *)(base + 64 * k);
+    int *own_status = (int *)(base + 256);
+    const size_t status_bytes = ((size_t)3 * ld * sizeof(int) + 255) / 256 * 256;
+    iv.xy_max = (double *)(base + 256 + status_bytes);
+    iv.mixed_max = iv.xy_max + (size_t)6 * h->p.N * ld;
+    iv.yaw_ref = iv.mixed_max + (size_t)6 * h->p.N * ld;
+    if (!d_status) d_status = own_status;
+    hipStream_t s = (hipStream_t)stream;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, s, true))) return rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, s, true))) return rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, s, true))) return rc;
     return TG_OK;
 }
 

@@ -288,6 +288,20 @@ class BatchedMPC12:
                                                  _ptr(buf["X"]), _ptr(buf["U"]), _ptr(buf["status"]),
                                                  _ptr(buf["iters"]), int(warm), _stream_ptr(stream)))
 
+    def solve_static(self, buf, stream=None, B=None):
+        """solve() for callers that cannot allocate device memory: cold start, inter-stage arrays in
+        the library's static device scratch (16 MiB per GPU; larger batches raise TgError)."""
+        B = buf["B"] if B is None else B
+        ld, N = buf["ld"], self.N
+        torch = _torch()
+        _check_dev(buf["x0"], 12, ld, torch.float64, "x0")
+        _check_dev(buf["ref"], 12 * (N + 1), ld, torch.float64, "ref")
+        _check_dev(buf["X"], 12 * (N + 1), ld, torch.float64, "X")
+        _check_dev(buf["U"], 4 * N, ld, torch.float64, "U")
+        capi.check(self.lib.tg_mpc12_solve_batch_static(self._h, B, ld, _ptr(buf["x0"]), _ptr(buf["ref"]),
+                                                        _ptr(buf["X"]), _ptr(buf["U"]), _ptr(buf["status"]),
+                                                        _ptr(buf["iters"]), _stream_ptr(stream)))
+
     def solve_stage(self, stage, buf, stream=None, B=None):
         """One stage with the upstream solution already in buf['X'] (stage-by-stage parity)."""
         B = buf["B"] if B is None else B
