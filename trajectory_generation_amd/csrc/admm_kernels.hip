@@ -27,6 +27,18 @@
 #ifndef TG_ABLATE
 #define TG_ABLATE 0   // development, bit mask: 1 = no MFMA, 2 = no rhs phase, 4 = no projection phase
 #endif
+#ifndef TG_VARIANTS
+#define TG_VARIANTS 0xFFFFFFFFu   // development: which kernel variants launch_admm compiles (see TG_HAS there)
+#endif
+#define TG_HAS(b) ((TG_VARIANTS >> (b)) & 1u)
+// development: -DTG_STAMP accumulates the shader-clock time of every phase of an iteration per wave
+// (workgroup 0) and leaves the sums in row 0 of U, [wave][8] (tools/phase_stamps.py)
+#ifdef TG_STAMP
+#define STAMP(i) do { __builtin_amdgcn_s_waitcnt(0); const long long now__ = (long long)__builtin_amdgcn_s_memtime(); \
+                      if ((i) > 0) stamp_acc[(i) - 1] += now__ - stamp_last; stamp_last = now__; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 namespace tg {
 
@@ -78,7 +90,16 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
 //   BGT  l = u of the dynamics rows of step 0 (-x0); those of the later steps are zero
 //   CTAB per axis and slot: step size, lower and upper bound; then the reduction scratch
-template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR>
+// SM:    the box rows' z and y are kept as one number s = alpha zt + (1 - alpha) z + y/rho, the
+//        argument of the last projection: z = clamp(s, l, u), y/rho = s - z bit for bit, so the pair is
+//        recomputed where it is used and a cell needs a register less per slot.  Valid when every
+//        box contains zero (z = y = 0 at a cold start is then s = 0) and the boxes do not change
+//        between warm-started calls; the host checks both (not MIXED).
+// QL:    q of the cells' position slots lives in LDS (region QV) instead of registers.
+// UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
+//        operator's own are zero).
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
+          bool SM = false, bool QL = false, int UK = 2>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -146,7 +167,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int WEQ = (SEP ? 2 : 1) * (n_int + S) * 16;
     const int WMX = WEQ + (ncell * D + D) * 16;
     const int SB = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);                   // LR: C r of every block, [blocks][sb_rows][16]
-    const int ZERO = SB + (LR ? P.lr_np * (n_int / nb) * P.sb_rows * 16 : 0);
+    const int QV = SB + (LR ? P.lr_np * (n_int / nb) * P.sb_rows * 16 : 0);   // QL: q of every cell, [ncell + 1][16]
+    const int ZERO = QV + (QL ? (ncell + 1) * 16 : 0);
     const int BGT = ZERO + 8 * 16;                                           // [NAX][D][16] -x0: l = u of the step-0 rows
     const int CTAB = BGT + NAX * D * 16;                                     // [NAX][S][3] rho, lb, ub
     unsigned long long *red = (unsigned long long *)(lds + CTAB + NAX * S * 3 + 1); // [9][16] maxima
@@ -169,11 +191,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     __syncthreads();
 
     // ------------------------------------------------------------ per-thread cell state
-    double x[MAXC][S], zb[MAXC][S], yb[MAXC][S];   // variables and their identity box rows
+    static_assert(!SM || !MIXED, "the two-axis stage's boxes change from call to call");
+    // variables and their identity box rows (SM: zb holds s, yb is not kept)
+    double x[MAXC][S], zb[MAXC][S], yb[SM ? 1 : MAXC][SM ? 1 : S];
     // dynamics rows of the cell: only y is kept.  Their z equals the bound b (l = u) after every
     // projection, and b is -x0 at step 0 and zero elsewhere, so both are read through i_bg.
     double yg[MAXC][D];
-    double q[MAXC];                                // q of the position slot
+    double q[QL ? 1 : MAXC];                       // q of the position slot
     double hiv[MIXED ? MAXC : 1][2];               // XY: |v|, |a| box of the cell (per instance)
     // XY mixed rows (mpc_12state.cpp:600-630): the 6 rows of step m = g, g + NT/16, ... belong to
     // thread group g as a unit of their own, whichever thread owns the two cells of that step.
@@ -238,6 +262,18 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         }
     }
 
+    // box of slot k of the thread's cell cc
+    auto box_of = [&](int cc, int k, double &lo, double &hi) __attribute__((always_inline)) {
+        if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
+        else if (REGC) { hi = c_hi[cc][k]; lo = k == 0 ? c_lo0[cc] : -hi; }
+        else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+    };
+    // SM: z and y/rho of a box row from s
+    auto zy_of = [&](int cc, int k, double lo, double hi, double &zv, double &yv) __attribute__((always_inline)) {
+        if constexpr (SM) { const double sv = zb[cc][k]; zv = clampd(sv, lo, hi); yv = sv - zv; }
+        else { zv = zb[cc][k]; yv = yb[cc][k]; }
+    };
+
     // Start the slot's instance `inst` (fresh slots only; the others keep their state): iterates
     // zero or the previous solve's, q, the step-0 bound, the per-instance boxes, and the w of the
     // first rhs.  Returns the slot's part of ||q||_inf.
@@ -260,9 +296,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             for (int k = 0; k < NAX; k++)
                 if (ax == k) { abase = P.axis_base[k]; x0r = P.x0_row[k]; refoff = P.ref_off[k]; qw = P.qw[k]; }
             double zg0[D], b0[D];
-            q[cc] = 0.0;
+            double qc = 0.0;
 #pragma unroll
-            for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; yb[cc][k] = 0.0; }
+            for (int k = 0; k < S; k++) { x[cc][k] = 0.0; zb[cc][k] = 0.0; if constexpr (!SM) yb[cc][k] = 0.0; }
 #pragma unroll
             for (int k = 0; k < D; k++) { zg0[k] = 0.0; yg[cc][k] = 0.0; b0[k] = 0.0; }
             if (MIXED) {
@@ -270,8 +306,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 hiv[cc][1] = lds[i_ct[cc] + 2 * 3 + 2];
             }
             if (act && valid) {
-                q[cc] = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
-                qmax = fmax(qmax, fabs(q[cc]));
+                qc = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
+                qmax = fmax(qmax, fabs(qc));
                 if (st == 0) {
 #pragma unroll
                     for (int k = 0; k < D; k++) {
@@ -289,8 +325,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         x[cc][k] = a.warm[w0 + (size_t)k * a.ldw];
-                        zb[cc][k] = a.warm[w0 + (size_t)(n_int + k) * a.ldw];
-                        yb[cc][k] = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw];
+                        zb[cc][k] = a.warm[w0 + (size_t)(n_int + k) * a.ldw];   // SM: this row holds s
+                        if constexpr (!SM) yb[cc][k] = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw];
                     }
                     const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
 #pragma unroll
@@ -302,6 +338,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             }
             // w of the cell's rows for the first rhs (unused cells write the spare rows at the end)
             const int cw = act ? c : ncell;
+            if constexpr (QL) lds[QV + cw * 16 + t] = qc; else q[cc] = qc;
 #pragma unroll
             for (int k = 0; k < D; k++) {
                 lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (zg0[k] - yg[cc][k]);
@@ -350,6 +387,54 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         if ((lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
     }
 
+    // ---- streamed operators (KSREG == 0): a wave's fragments lie in P.Wfrag in the order it uses
+    // them -- first-stage items (each a whole number of ring rounds), then, in the low-rank form,
+    // the D_I / U_I fragments of its tiles -- so one ring of PD loads in flight serves the whole
+    // MFMA phase.  The items' LDS offsets are wave-uniform and looked up once, here.
+    constexpr bool STREAM = KSREG == 0;
+    constexpr int PD = kRingDepth;
+    constexpr int KD = 4 + UK;                      // fragments of a second-stage item
+    const int laneoff = (lane >> 4) * 16 + (lane & 15);
+    // wave-uniform base of the stream; a load is base + lane, so that the base stays in scalar registers
+    const double *ws = STREAM ? P.Wfrag + (size_t)P.wave_off[wave] * 64 : nullptr;
+    const unsigned ulane = (unsigned)lane;
+    // Keeps a wave-uniform LDS offset in a scalar register and its per-lane address out of the
+    // loop-invariant code the compiler would hoist (and then spill: one address per item).
+    auto uniform_off = [](int v) __attribute__((always_inline)) -> int {
+        v = __builtin_amdgcn_readfirstlane(v);
+        asm volatile("" : "+s"(v));
+        return v;
+    };
+    const int pstride = LR ? (n_int / nb) * P.sb_rows * 16 : 0;   // doubles between the partial sums of C r
+    const int njt = (STREAM && LR) ? P.wj_cnt[wave] : 0;
+    int s1_b[MAXIT], s1_o[MAXIT], s1_nr[MAXIT], s1_rows[MAXIT], s2_r[MAXIT], s2_s[MAXIT], s2_rows[MAXIT];
+    bool s1_two[MAXIT], s2_two[MAXIT];
+    if constexpr (STREAM) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+            const bool in = it < nit;
+            const int grp = in ? P.wi_grp[wave][it] : 0, rb = in ? P.wi_rb[wave][it] : 0;
+            const int k0 = in ? P.wi_k0[wave][it] : 0, part = in ? P.wi_part[wave][it] : 0;
+            const int blk = P.grp_first[grp];
+            s1_two[it] = PAIR && P.grp_cnt[grp] == 2;
+            s1_nr[it] = in ? P.wi_nr[wave][it] : 0;
+            s1_b[it] = V0 + (blk * nb + 4 * k0) * 16;
+            s1_o[it] = LR ? SB + part * pstride + (blk * P.sb_rows + rb * 16) * 16 : VX + (blk * nb + rb * 16) * 16;
+            s1_rows[it] = nb - rb * 16;
+        }
+#pragma unroll
+        for (int jt = 0; jt < MAXIT; jt++) {
+            const bool in = jt < njt;
+            const int grp = in ? P.wj_grp[wave][jt] : 0, I = in ? P.wj_rb[wave][jt] : 0;
+            const int blk = P.grp_first[grp];
+            s2_two[jt] = PAIR && P.grp_cnt[grp] == 2;
+            s2_r[jt] = V0 + (blk * nb + I * 16) * 16;
+            s2_s[jt] = SB + (blk * P.sb_rows + I * P.lr_q) * 16;
+            s2_rows[jt] = nb - I * 16;
+        }
+    }
+    double af[STREAM ? PD : 1];
+
     const int max_iter = P.max_iter, check = P.check, fine = P.check_fine;
     const double eps_pinf = P.eps_prim_inf;
     if (__syncthreads_and((done && exhausted) ? 1 : 0)) return;   // nothing to solve in this tile
@@ -361,12 +446,25 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // u'(dy)+ + l'(dy)- are accumulated (pin_n, pin_l).
     double part[MAXC][S];
     double pin_n = 0.0, pin_l = 0.0;
+#ifdef TG_STAMP
+    long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+#endif
     auto step = [&](auto chk_c) __attribute__((always_inline)) {
         // The iterates must not depend on whether this is a checking iteration (a slot meets them
         // at different points of its run depending on its neighbours): every rounding is written
         // out, and the compiler may not fuse differently in the two instantiations.
 #pragma clang fp contract(off)
         constexpr bool CHK = decltype(chk_c)::value;
+#ifdef TG_STAMP
+        { __builtin_amdgcn_s_waitcnt(0); const long long now__ = (long long)__builtin_amdgcn_s_memtime();
+          if (stamp_last) stamp_acc[7] += now__ - stamp_last; stamp_last = now__; }
+#else
+        STAMP(0);
+#endif
+        if constexpr (STREAM) {   // the ring's first fragments travel while the rhs is formed
+#pragma unroll
+            for (int p = 0; p < PD; p++) af[p] = ws[ulane + p * 64];
+        }
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
         // Cells are handled in groups of G: every LDS read of the group is issued before its first
         // LDS write.  The compiler cannot tell that the regions do not overlap, so a write between
@@ -375,7 +473,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         constexpr int G = MIXED ? 2 : (MAXC <= 2 ? MAXC : (LR ? 2 : 1));
 #pragma unroll
         for (int c0 = 0; c0 < ((TG_ABLATE & 2) ? 0 : MAXC); c0 += G) {
-            double wn[G][D], wo[G][D], rr[G][S], mixc[G][3];
+            double wn[G][D], wo[G][D], rr[G][S], mixc[G][3], bx[SM ? G : 1][S][2], qv[G];
 #pragma unroll
             for (int j = 0; j < G; j++) {
                 const int cc = c0 + j;
@@ -386,9 +484,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     wo[j][k] = lds[WEQ + (cw * D + k) * 16 + t];
                     wn[j][k] = lds[i_wnext[cc] + k * 16];
                 }
-                if constexpr (G > 1) {
+                if constexpr (QL) qv[j] = lds[QV + cw * 16 + t]; else qv[j] = q[cc];
+                if constexpr (G > 1 || SM) {
 #pragma unroll
-                    for (int k = 0; k < S; k++) rr[j][k] = REGC ? c_rho[cc][k] : lds[i_ct[cc] + k * 3];
+                    for (int k = 0; k < S; k++) {
+                        rr[j][k] = REGC ? c_rho[cc][k] : lds[i_ct[cc] + k * 3];
+                        if constexpr (SM) box_of(cc, k, bx[j][k][0], bx[j][k][1]);
+                    }
                 }
                 mixc[j][0] = mixc[j][1] = mixc[j][2] = 0.0;
                 if (MIXED) {
@@ -408,15 +510,19 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (cc >= MAXC) continue;
 #pragma unroll
                 for (int l = 0; l < D; l++) {
-                    double acc = __builtin_fma(G > 1 ? rr[j][l] : lds[i_ct[cc] + l * 3], zb[cc][l] - yb[cc][l], sigma * x[cc][l]) - wo[j][l];
-                    if (l == 0) acc -= q[cc];
+                    double zv, yv;
+                    zy_of(cc, l, SM ? bx[j][l][0] : 0.0, SM ? bx[j][l][1] : 0.0, zv, yv);
+                    double acc = __builtin_fma((G > 1 || SM) ? rr[j][l] : lds[i_ct[cc] + l * 3], zv - yv, sigma * x[cc][l]) - wo[j][l];
+                    if (l == 0) acc -= qv[j];
 #pragma unroll
                     for (int k = 0; k <= l; k++) acc = __builtin_fma(chain_coef<D>(k, l, dt, c2), wn[j][k], acc);
                     if (MIXED && l >= 1) acc += mixc[j][l];
                     racc[j][l] = acc;
                 }
                 // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
-                racc[j][D] = __builtin_fma(G > 1 ? rr[j][D] : lds[i_ct[cc] + D * 3], zb[cc][D] - yb[cc][D], __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
+                double zvD, yvD;
+                zy_of(cc, D, SM ? bx[j][D][0] : 0.0, SM ? bx[j][D][1] : 0.0, zvD, yvD);
+                racc[j][D] = __builtin_fma((G > 1 || SM) ? rr[j][D] : lds[i_ct[cc] + D * 3], zvD - yvD, __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
             }
             if constexpr (MIXED) {
                 // The two axes are interchangeable in K = P + sigma I + A' rho A (same weights, same
@@ -438,7 +544,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
             }
         }
+        STAMP(1);
         __syncthreads();
+        STAMP(2);
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
         // D[16 rows x 16 instances] += A[16 x 4] * B[4 x 16]: A = operator fragment (registers
         // when it fits, else streamed from L2 through a prefetch ring), B = rhs rows from LDS
@@ -477,7 +585,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 };
                 if (nit > 0) { if (PAIR && two_r) run(std::true_type{}); else run(std::false_type{}); }
             }
+            STAMP(3);
             __syncthreads();
+            STAMP(4);
             {   // stage 2: this wave's tile, D_I r_I + U_I (s^(0) + ... + s^(3))
                 const int blk = P.grp_first[grp_2];
                 const bool two = PAIR && P.grp_cnt[grp_2] == 2;
@@ -518,224 +628,200 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (P.wj_cnt[wave] > 0) { if (PAIR && two) run(std::true_type{}); else run(std::false_type{}); }
             }
         } else if constexpr (LR) {
-            // Block-row low-rank form: stage 1, s = C r for every block (the stacked C streams from
-            // L2 like a dense operator with few rows); stage 2, per 16-row tile I,
-            // xt_I = D_I r_I + U_I s_I written over r_I: only the tile's own wave reads or writes
-            // those rows after the barrier, so rhs and xt share one vector without another barrier.
-            constexpr int PD = kRingDepth;
-            const int q = P.lr_q, crb = P.lr_crb, uk = P.lr_uk, srows = nrb * q;
-            // The second stage's items are short (4 + uk MFMAs) and would each wait a full L2
-            // round trip for their fragments: the first item's are requested before stage 1, the
-            // next item's while the current one computes.
-            constexpr int KD = 6;                      // 4 k-steps of D_I + at most 2 of U_I
-            const int njt = P.wj_cnt[wave];
-            double afn[2][KD];
-            auto load_frags = [&](int jt, double *dst) __attribute__((always_inline)) {
-                if (jt < njt) {
-                    const int grp = P.wj_grp[wave][jt], I = P.wj_rb[wave][jt];
-                    const double *fr = P.DUfrag + ((size_t)P.grp_op[grp] * nrb + I) * (4 + uk) * 64 + lane;
-#pragma unroll
-                    for (int kk = 0; kk < KD; kk++) dst[kk] = kk < 4 + uk ? fr[kk * 64] : 0.0;
-                }
-            };
-            load_frags(0, afn[0]);
+            // Block-row low-rank form: stage 1, s = C r for every block as two partial sums (the
+            // k range of a row block of the stacked C is cut in two items, so that the eight waves
+            // share the work evenly); stage 2, per 16-row tile I, xt_I = D_I r_I + U_I s_I written
+            // over r_I: only the tile's own wave reads or writes those rows after the barrier, so
+            // rhs and xt share one vector without another barrier.  The wave's fragments arrive
+            // through the ring in the order of use; the first PD were requested at the top of the
+            // iteration, and the second stage's first ones are requested during the first stage.
+            const double *wp = ws + PD * 64;
+            const int nb16 = nb * 16, sb16 = P.sb_rows * 16;
+            const bool np2 = P.lr_np == 2;
 #pragma unroll
             for (int it = 0; it < MAXIT; it++) {
                 if (it < nit) {
-                    const int grp = P.wi_grp[wave][it], rb = P.wi_rb[wave][it];
-                    const bool two = PAIR && P.grp_cnt[grp] == 2;
-                    const double *bp0 = v0 + (P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15);
-                    const double *bp1 = bp0 + (size_t)nb * 16;
-                    const double *Mrow = P.Mfrag + ((size_t)P.grp_op[grp] * crb + rb) * P.ks_alloc * 64 + lane;
+                    const double *b0 = lds + uniform_off(s1_b[it]) + laneoff;
                     auto run = [&](auto two_c) __attribute__((always_inline)) {
                         constexpr bool TWO = decltype(two_c)::value;
-                        double af[PD];
-#pragma unroll
-                        for (int p = 0; p < PD; p++) af[p] = Mrow[p * 64];
+                        // two independent accumulation chains either way: a dependent MFMA issues
+                        // every 128 clocks, two alternating chains every 64
                         d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
-                        const int full = ks / PD, rem = ks - full * PD;
-                        const double *mp = Mrow + PD * 64, *b0 = bp0, *b1 = bp1;
-                        for (int f = 0; f < full; f++) {
+                        const double *b = b0;
+                        for (int r = 0; r < s1_nr[it]; r++) {
 #pragma unroll
                             for (int p = 0; p < PD; p++) {
-                                const double bf0 = b0[p * 64];
-                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                const double bf0 = b[p * 64];
+                                if (TWO || !(p & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c1, 0, 0, 0);
                                 if constexpr (TWO) {
-                                    const double bf1 = b1[p * 64];
+                                    const double bf1 = b[nb16 + p * 64];
                                     c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
                                 }
-                                af[p] = mp[p * 64];
+                                af[p] = wp[ulane + p * 64];
                             }
-                            mp += PD * 64; b0 += PD * 64; b1 += PD * 64;
+                            wp += PD * 64; b += PD * 64;
                         }
+                        if constexpr (!TWO) {
 #pragma unroll
-                        for (int p = 0; p < PD; p++) {
-                            if (p < rem) {
-                                const double bf0 = b0[p * 64];
-                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
-                                if constexpr (TWO) {
-                                    const double bf1 = b1[p * 64];
-                                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
-                                }
-                            }
+                            for (int r = 0; r < 4; r++) c0[r] += c1[r];
                         }
-                        double *o0 = lds + SB + ((size_t)P.grp_first[grp] * P.sb_rows + rb * 16 + (lane >> 4)) * 16 + (lane & 15);
-                        const int row0 = rb * 16 + (lane >> 4);
+                        // rows past the stacked C are zero rows of the operator: stored like the others
+                        double *o0 = lds + uniform_off(s1_o[it]) + laneoff;
 #pragma unroll
-                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < srows) o0[r * 64] = c0[r];
+                        for (int r = 0; r < 4; r++) o0[r * 64] = c0[r];
                         if constexpr (TWO) {
-                            double *o1 = o0 + (size_t)P.sb_rows * 16;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (row0 + 4 * r < srows) o1[r * 64] = c1[r];
+                            for (int r = 0; r < 4; r++) o0[sb16 + r * 64] = c1[r];
                         }
                     };
-                    if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
+                    if (PAIR && s1_two[it]) run(std::true_type{}); else run(std::false_type{});
                 }
             }
+            STAMP(3);
             __syncthreads();
+            STAMP(4);
+            // wp now points at fragment PD of the second stage: fragment j + PD is wp[j * 64]
 #pragma unroll
             for (int jt = 0; jt < MAXIT; jt++) {
                 if (jt < njt) {
-                    if (jt + 1 < MAXIT) load_frags(jt + 1, afn[(jt + 1) & 1]);
-                    const double *af = afn[jt & 1];
-                    const int grp = P.wj_grp[wave][jt], I = P.wj_rb[wave][jt];
-                    const bool two = PAIR && P.grp_cnt[grp] == 2;
-                    const int blk = P.grp_first[grp];
-                    double *r0p = v0 + ((size_t)blk * nb + I * 16 + (lane >> 4)) * 16 + (lane & 15);
-                    const double *s0p = lds + SB + ((size_t)blk * P.sb_rows + I * q + (lane >> 4)) * 16 + (lane & 15);
+                    double *r0p = lds + uniform_off(s2_r[jt]) + laneoff;
+                    const double *s0p = lds + uniform_off(s2_s[jt]) + laneoff;
                     auto run = [&](auto two_c) __attribute__((always_inline)) {
                         constexpr bool TWO = decltype(two_c)::value;
                         double bf0[KD], bf1[TWO ? KD : 1];
 #pragma unroll
-                        for (int kk = 0; kk < KD; kk++) {
-                            const bool in = kk < 4 + uk;
-                            const double *b = kk < 4 ? r0p + kk * 64 : s0p + (kk - 4) * 64;
-                            bf0[kk] = in ? b[0] : 0.0;
-                            if constexpr (TWO) bf1[kk] = in ? b[(size_t)(kk < 4 ? nb : P.sb_rows) * 16] : 0.0;
+                        for (int kk = 0; kk < 4; kk++) {
+                            bf0[kk] = r0p[kk * 64];
+                            if constexpr (TWO) bf1[kk] = r0p[nb16 + kk * 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < UK; u++) {      // the two partial sums are added on the way in
+                            bf0[4 + u] = s0p[u * 64];
+                            if constexpr (TWO) bf1[4 + u] = s0p[sb16 + u * 64];
+                            if (np2) {
+                                bf0[4 + u] += s0p[pstride + u * 64];
+                                if constexpr (TWO) bf1[4 + u] += s0p[sb16 + pstride + u * 64];
+                            }
                         }
                         d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
 #pragma unroll
                         for (int kk = 0; kk < KD; kk++) {
-                            if (kk < 4 + uk) {
-                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf0[kk], c0, 0, 0, 0);
-                                if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], bf1[kk], c1, 0, 0, 0);
-                            }
+                            const int j = jt * KD + kk;          // compile-time after unrolling
+                            if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[j % PD], bf0[kk], c0, 0, 0, 0);
+                            else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[j % PD], bf0[kk], c1, 0, 0, 0);
+                            if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[j % PD], bf1[kk], c1, 0, 0, 0);
+                            if (j + PD < MAXIT * KD) af[j % PD] = wp[ulane + j * 64];
                         }
-                        const int row0 = I * 16 + (lane >> 4);   // rows past the block are MFMA padding
+                        if constexpr (!TWO) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) r0p[r * 64] = c0[r];
+                            for (int r = 0; r < 4; r++) c0[r] += c1[r];
+                        }
+                        const int rows = s2_rows[jt] - (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (4 * r < rows) r0p[r * 64] = c0[r];
                         if constexpr (TWO) {
-                            double *r1p = r0p + (size_t)nb * 16;
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) r1p[r * 64] = c1[r];
+                            for (int r = 0; r < 4; r++) if (4 * r < rows) r0p[nb16 + r * 64] = c1[r];
                         }
                     };
-                    if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
+                    if (PAIR && s2_two[jt]) run(std::true_type{}); else run(std::false_type{});
                 }
             }
         } else
         {
             // with a separate xt vector (SEP) an item's rows are stored as soon as they are done;
             // otherwise xt overwrites the rhs and the stores wait for every wave's last read
-            auto store = [&](int grp, int rb, bool two, const d4 &c0, const d4 &c1) __attribute__((always_inline)) {
-                double *o0 = vx + (KSREG > 0 ? boff_r + rb * 256 : (P.grp_first[grp] * nb + rb * 16 + (lane >> 4)) * 16 + (lane & 15));
-                const int row0 = rb * 16 + (lane >> 4);   // rows past the block are MFMA padding
+            auto store = [&](int ooff, int rows_left, bool two, const d4 &c0, const d4 &c1) __attribute__((always_inline)) {
+                double *o0 = lds + uniform_off(ooff) + laneoff;
+                const int rows = rows_left - (lane >> 4);   // rows past the block are MFMA padding
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[r * 64] = c0[r];
+                for (int r = 0; r < 4; r++) if (4 * r < rows) o0[r * 64] = c0[r];
                 if (PAIR && two) {
                     double *o1 = o0 + (size_t)nb * 16;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o1[r * 64] = c1[r];
+                    for (int r = 0; r < 4; r++) if (4 * r < rows) o1[r * 64] = c1[r];
                 }
             };
             d4 acc0[SEP ? 1 : MAXIT], acc1[(PAIR && !SEP) ? MAXIT : 1];
-#pragma unroll
-            for (int it = 0; it < MAXIT; it++) {
-                if (it < nit) {
-                    const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
-                    const bool two = KSREG > 0 ? two_r : (PAIR && P.grp_cnt[grp] == 2);
-                    const double *bp0 = v0 + (KSREG > 0 ? boff_r : (P.grp_first[grp] * nb + (lane >> 4)) * 16 + (lane & 15));
+            if constexpr (KSREG > 0) {
+                // ks <= KSREG (host dispatch): all B operands are fetched before the first
+                // MFMA and the chain has no branches; fragments past ks are zero and their B
+                // rows are whatever finite values follow the block in LDS
+                if (nit > 0) {
+                    const double *bp0 = v0 + boff_r;
                     const double *bp1 = bp0 + (size_t)nb * 16;
-                    if constexpr (KSREG > 0) {
-                        // ks <= KSREG (host dispatch): all B operands are fetched before the first
-                        // MFMA and the chain has no branches; fragments past ks are zero and their B
-                        // rows are whatever finite values follow the block in LDS
+                    auto run = [&](auto two_c) __attribute__((always_inline)) {
+                        constexpr bool TWO = decltype(two_c)::value;
+                        double bf0[KSREG], bf1[TWO ? KSREG : 1];
+#pragma unroll
+                        for (int kk = 0; kk < KSREG; kk++) {
+                            bf0[kk] = bp0[kk * 64];
+                            if constexpr (TWO) bf1[kk] = bp1[kk * 64];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA chain
+                        // A dependent MFMA issues every 128 clocks, an independent one every 64:
+                        // a single product is split over two accumulators (even / odd k steps),
+                        // in case the wave has its SIMD to itself during this phase.
+                        d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+#pragma unroll
+                        for (int kk = 0; kk < KSREG; kk++) {
+#if !(TG_ABLATE & 1)
+                            if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c0, 0, 0, 0);
+                            else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c1, 0, 0, 0);
+                            if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf1[kk], c1, 0, 0, 0);
+#else
+                            c0[0] += mreg[kk] * bf0[kk];
+                            if constexpr (TWO) c1[0] += mreg[kk] * bf1[kk];
+#endif
+                        }
+                        if constexpr (!TWO) {
+#pragma unroll
+                            for (int r = 0; r < 4; r++) c0[r] += c1[r];
+                        }
+                        if constexpr (SEP) store(VX + P.grp_first[grp_r] * nb * 16 + rb_r * 256, nb - rb_r * 16, TWO, c0, c1);
+                        else { acc0[0] = c0; if constexpr (PAIR) acc1[0] = c1; }
+                    };
+                    if (PAIR && two_r) run(std::true_type{}); else run(std::false_type{});
+                }
+            } else {
+                // the wave's items follow one another in its fragment stream (each a whole number
+                // of ring rounds, padded with zero fragments): the ring never drains between items,
+                // and its first PD fragments were requested at the top of the iteration
+                const double *wp = ws + PD * 64;
+                const int nb16 = nb * 16;
+#pragma unroll
+                for (int it = 0; it < MAXIT; it++) {
+                    if (it < nit) {
+                        const double *b0 = lds + uniform_off(s1_b[it]) + laneoff;
                         auto run = [&](auto two_c) __attribute__((always_inline)) {
                             constexpr bool TWO = decltype(two_c)::value;
-                            double bf0[KSREG], bf1[TWO ? KSREG : 1];
-#pragma unroll
-                            for (int kk = 0; kk < KSREG; kk++) {
-                                bf0[kk] = bp0[kk * 64];
-                                if constexpr (TWO) bf1[kk] = bp1[kk * 64];
-                            }
-                            __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA chain
-                            // A dependent MFMA issues every 128 clocks, an independent one every 64:
-                            // a single product is split over two accumulators (even / odd k steps),
-                            // in case the wave has its SIMD to itself during this phase.
                             d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
+                            const double *b = b0;
+                            for (int r = 0; r < s1_nr[it]; r++) {
 #pragma unroll
-                            for (int kk = 0; kk < KSREG; kk++) {
-#if !(TG_ABLATE & 1)
-                                if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c0, 0, 0, 0);
-                                else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c1, 0, 0, 0);
-                                if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf1[kk], c1, 0, 0, 0);
-#else
-                                c0[0] += mreg[kk] * bf0[kk];
-                                if constexpr (TWO) c1[0] += mreg[kk] * bf1[kk];
-#endif
+                                for (int p = 0; p < PD; p++) {
+                                    // the fragment's last use comes before its slot is reloaded, so
+                                    // the load can land in the same registers
+                                    const double bf0 = b[p * 64];
+                                    if (TWO || !(p & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
+                                    else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c1, 0, 0, 0);
+                                    if constexpr (TWO) {
+                                        const double bf1 = b[nb16 + p * 64];
+                                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
+                                    }
+                                    af[p] = wp[ulane + p * 64];
+                                }
+                                wp += PD * 64; b += PD * 64;
                             }
                             if constexpr (!TWO) {
 #pragma unroll
                                 for (int r = 0; r < 4; r++) c0[r] += c1[r];
                             }
-                            if constexpr (SEP) store(grp, rb, TWO, c0, c1);
-                            else { acc0[0] = c0; if constexpr (PAIR) acc1[0] = c1; }
-                        };
-                        if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
-                    } else {
-                        // ring of kRingDepth fragments in flight; the fragment array carries
-                        // kRingDepth zero steps of padding, so the prefetch needs no bounds test and
-                        // the loop body has no branches (a branch makes the compiler drain the ring)
-                        constexpr int PD = kRingDepth;
-                        const double *Mrow = P.Mfrag + ((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc * 64 + lane;
-                        auto run = [&](auto two_c) __attribute__((always_inline)) {
-                            constexpr bool TWO = decltype(two_c)::value;
-                            double af[PD];
-#pragma unroll
-                            for (int p = 0; p < PD; p++) af[p] = Mrow[p * 64];
-                            d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
-                            const int full = ks / PD, rem = ks - full * PD;
-                            const double *mp = Mrow + PD * 64, *b0 = bp0, *b1 = bp1;
-                            for (int f = 0; f < full; f++) {
-#pragma unroll
-                                for (int p = 0; p < PD; p++) {
-                                    // the fragment's last use comes before its slot is reloaded, so
-                                    // the load can land in the same registers
-                                    const double bf0 = b0[p * 64];
-                                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
-                                    if constexpr (TWO) {
-                                        const double bf1 = b1[p * 64];
-                                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
-                                    }
-                                    af[p] = mp[p * 64];
-                                }
-                                mp += PD * 64; b0 += PD * 64; b1 += PD * 64;
-                            }
-#pragma unroll
-                            for (int p = 0; p < PD; p++) {
-                                if (p < rem) {
-                                    const double bf0 = b0[p * 64];
-                                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf0, c0, 0, 0, 0);
-                                    if constexpr (TWO) {
-                                        const double bf1 = b1[p * 64];
-                                        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[p], bf1, c1, 0, 0, 0);
-                                    }
-                                }
-                            }
-                            if constexpr (SEP) store(grp, rb, TWO, c0, c1);
+                            if constexpr (SEP) store(s1_o[it], s1_rows[it], TWO, c0, c1);
                             else { acc0[it] = c0; if constexpr (PAIR) acc1[it] = c1; }
                         };
-                        if (PAIR && two) run(std::true_type{}); else run(std::false_type{});
+                        if (PAIR && s1_two[it]) run(std::true_type{}); else run(std::false_type{});
                     }
                 }
             }
@@ -744,13 +830,15 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                 for (int it = 0; it < MAXIT; it++) {
                     if (it < nit) {
-                        const int grp = KSREG > 0 ? grp_r : P.wi_grp[wave][it], rb = KSREG > 0 ? rb_r : P.wi_rb[wave][it];
-                        store(grp, rb, KSREG > 0 ? two_r : P.grp_cnt[grp] == 2, acc0[it], acc1[PAIR ? it : 0]);
+                        if constexpr (KSREG > 0) store(VX + P.grp_first[grp_r] * nb * 16 + rb_r * 256, nb - rb_r * 16, two_r, acc0[it], acc1[PAIR ? it : 0]);
+                        else store(s1_o[it], s1_rows[it], s1_two[it], acc0[it], acc1[PAIR ? it : 0]);
                     }
                 }
             }
         }
+        STAMP(5);
         __syncthreads();
+        STAMP(6);
         // -------------------------------------------------------- relaxation, projection, dual
         if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; }
         {
@@ -797,12 +885,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         x[cc][k] = __builtin_fma(alpha, xt[j][k], oma * x[cc][k]);
-                        const double zr = __builtin_fma(alpha, xt[j][k], oma * zb[cc][k]);
-                        const double s = zr + yb[cc][k];
                         double lo, hi;   // a single cell at a time reads its constants where they are used
                         if constexpr (G > 1) { lo = bnd[j][k][0]; hi = bnd[j][k][1]; }
                         else if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
                         else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+                        double zo, yo;
+                        zy_of(cc, k, lo, hi, zo, yo);
+                        const double zr = __builtin_fma(alpha, xt[j][k], oma * zo);
+                        const double s = zr + yo;
                         const double zn = clampd(s, lo, hi);
                         if constexpr (CHK) {
                             double d = (G > 1 ? rr[j][k] : lds[i_ct[cc] + k * 3]) * (zr - zn);
@@ -812,8 +902,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             pin_l += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
                             part[cc][k] = d;
                         }
-                        yb[cc][k] = s - zn;
-                        zb[cc][k] = zn;
+                        if constexpr (SM) zb[cc][k] = s;
+                        else { yb[cc][k] = s - zn; zb[cc][k] = zn; }
                     }
                     // dynamics rows of this step: -x_k(i) + sum_l c_kl x_l(i-1) + [k = D-1] dt u(i-1)
 #pragma unroll
@@ -867,6 +957,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
             }
         }
+        STAMP(7);
     };
 
     // Checks come at `check`, then every `check_fine` (or every `check` when check_fine is 0), and
@@ -960,6 +1051,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     double pdiag = 0.0;
 #pragma unroll
                     for (int k = 0; k < NAX; k++) if (ax == k) pdiag = P.pdiag[k];
+                    double zc[S], yc[S];   // z and y/rho of the cell's box rows
+#pragma unroll
+                    for (int k = 0; k < S; k++) {
+                        double lo = 0.0, hi = 0.0;
+                        if constexpr (SM) box_of(cc, k, lo, hi);
+                        zy_of(cc, k, lo, hi, zc[k], yc[k]);
+                    }
                     double yn[D], mixc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                     for (int k = 0; k < D; k++) yn[k] = lds[i_wnext[cc] + k * 16];
@@ -974,11 +1072,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int l = 0; l < D; l++) {
                         const double px = l == 0 ? pdiag * x[cc][0] : 0.0;
-                        double aty = ct[l * 3] * yb[cc][l] - rho_eq * yg[cc][l];
+                        double aty = ct[l * 3] * yc[l] - rho_eq * yg[cc][l];
 #pragma unroll
                         for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
                         if (MIXED && l >= 1) aty += mixc[l];
-                        const double qq = l == 0 ? q[cc] : 0.0;
+                        const double qq = l == 0 ? (QL ? lds[QV + c * 16 + t] : q[QL ? 0 : cc]) : 0.0;
                         m_rd = fmax(m_rd, fabs(px + qq + aty));
                         m_px = fmax(m_px, fabs(px));
                         m_aty = fmax(m_aty, fabs(aty));
@@ -990,7 +1088,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             const double up = st < N - 1 ? xin[(D + S) * 16] : x[cc][D];
                             px += P.smooth * ((x[cc][D] - um) + (x[cc][D] - up));
                         }
-                        const double aty = ct[D * 3] * yb[cc][D] + dt * yn[D - 1];
+                        const double aty = ct[D * 3] * yc[D] + dt * yn[D - 1];
                         m_rd = fmax(m_rd, fabs(px + aty));
                         m_px = fmax(m_px, fabs(px));
                         m_aty = fmax(m_aty, fabs(aty));
@@ -999,9 +1097,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         if (k < D || st < N) {
-                            m_rp = fmax(m_rp, fabs(x[cc][k] - zb[cc][k]));
+                            m_rp = fmax(m_rp, fabs(x[cc][k] - zc[k]));
                             m_ax = fmax(m_ax, fabs(x[cc][k]));
-                            m_z = fmax(m_z, fabs(zb[cc][k]));
+                            m_z = fmax(m_z, fabs(zc[k]));
                         }
                     }
                     // ... dynamics rows ...
@@ -1101,8 +1199,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                             for (int k = 0; k < S; k++) {
                                 a.warm[w0 + (size_t)k * a.ldw] = x[cc][k];
-                                a.warm[w0 + (size_t)(n_int + k) * a.ldw] = zb[cc][k];
-                                a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] = yb[cc][k];
+                                a.warm[w0 + (size_t)(n_int + k) * a.ldw] = zb[cc][k];   // SM: s
+                                if constexpr (!SM) a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] = yb[cc][k];
                             }
                             const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
 #pragma unroll
@@ -1172,6 +1270,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             if (__syncthreads_and((done && exhausted) ? 1 : 0)) break;
         }
     }
+#ifdef TG_STAMP
+    if (blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 8; i++) a.U[wave * 8 + i] = (double)stamp_acc[i];
+#endif
 }
 
 // ---------------------------------------------------------------- full q, l, u per instance
@@ -1349,14 +1451,17 @@ size_t admm_lds_bytes(const StageDev &P)
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
     size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
                   (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D +
-                  (P.lr ? (size_t)P.lr_np * (P.n_int / P.nb) * P.sb_rows : 0);
+                  (P.lr ? (size_t)P.lr_np * (P.n_int / P.nb) * P.sb_rows : 0) + (P.ql ? (size_t)ncell + 1 : 0);
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves + 1) * 16 * sizeof(double);
 }
 
-template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false>
+template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
+          bool SM = false, bool QL = false, int UK = 2>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK>;
+    if ((P.sm != 0) != SM || (P.ql != 0) != QL) return hipErrorInvalidValue;   // the LDS layout follows P.ql
+    if (KSREG == 0 && (!P.Wfrag || (LR && (P.lr_np > 2 || P.lr_ukp != UK)))) return hipErrorInvalidValue;
     const size_t lds_bytes = admm_lds_bytes(P);
     // the dynamic LDS limit of a kernel is per device and sticky: raise it when it has to grow
     // (per-variant caches, shared by every handle and host thread of the process)
@@ -1437,11 +1542,22 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     single.separate_xt = 0;
     int needj = 0;
     for (int w = 0; w < P.nwaves; w++) needj = P.wj_cnt[w] > needj ? P.wj_cnt[w] : needj;
+    // Development builds compile a subset of the variants (-DTG_VARIANTS=mask, bit = TG_HAS index).
+    StageDev plain = P;          // variants without the s form / q in LDS
+    plain.sm = 0; plain.ql = 0;
+    if (admm_lds_bytes(plain) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
+    single.sm = 0; single.ql = 0;
     if (P.lr && P.lr_np == 4) {
         // low-rank operators with register-resident fragments (6-DOF, short horizons)
         if (P.D == 2 && P.nax == 3 && !P.mixed && sym && sep && needc <= 2 && needi <= 1 && needj <= 1 && fits(16) &&
-            P.lr_crb == 1 && P.lr_uk == 1)
-            return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(P, a, s);
+            P.lr_crb == 1 && P.lr_uk == 1) {
+#if TG_HAS(0)
+            if (P.sm && !P.ql) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true, true, false>(P, a, s);
+#endif
+#if TG_HAS(1)
+            return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(plain, a, s);
+#endif
+        }
         *why = "internal: no register-resident low-rank variant for this stage";
         return hipErrorInvalidValue;
     }
@@ -1449,29 +1565,59 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
         // block-row low-rank operators: rhs and xt share one vector
         if (sep) { *why = "internal: the low-rank form keeps rhs and xt in one vector"; return hipErrorInvalidValue; }
         const int items = needi > needj ? needi : needj;
-        if (P.D == 2 && P.nax == 3 && !P.mixed && needc <= 5 && items <= 3)
-            return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(P, a, s);
+        if (P.D == 2 && P.nax == 3 && !P.mixed && needc <= 5 && items <= 3) {
+#if TG_HAS(2)
+            if (P.sm && P.ql && P.lr_ukp == 1) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s);
+#endif
+#if TG_HAS(3)
+            return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(plain, a, s);
+#endif
+        }
+#if TG_HAS(4)
         if (P.D == 3 && P.nax == 2 && P.mixed && needc <= 2 && items <= 2)
-            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, false, true>(P, a, s);
+            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, false, true>(plain, a, s);
+#endif
+#if TG_HAS(5)
         if (P.D == 3 && P.nax == 2 && P.mixed && needc <= 4 && items <= 4)
-            return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false, true>(P, a, s);
+            return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false, true>(plain, a, s);
+#endif
+#if TG_HAS(6)
         if (P.D == 3 && P.nax == 1 && !P.mixed && needc <= 2 && items <= 2)
-            return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, false, true>(P, a, s);
+            return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, false, true>(plain, a, s);
+#endif
         *why = "horizon too long for the compiled kernel variants";
         return hipErrorInvalidValue;
     }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
-        if (sym && sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(P, a, s);
-        if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(P, a, s);
+#if TG_HAS(7)
+        if (sym && sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(plain, a, s);
+#endif
+#if TG_HAS(8)
+        if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(plain, a, s);
+#endif
+#if TG_HAS(9)
         if (needc <= 8 && needi <= 4) return launch_admm_t<512, 2, 3, false, 8, 4, true, 0, false>(single, a, s);
+#endif
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
-        if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(P, a, s);
-        if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(P, a, s);
+#if TG_HAS(10)
+        if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(plain, a, s);
+#endif
+#if TG_HAS(11)
+        if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(plain, a, s);
+#endif
+#if TG_HAS(12)
         if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false>(single, a, s);
+#endif
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
-        if (sym && sep && needc <= 1 && needi <= 1 && fits(21)) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(P, a, s);
-        if (sym && sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(P, a, s);
+#if TG_HAS(13)
+        if (sym && sep && needc <= 1 && needi <= 1 && fits(21)) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(plain, a, s);
+#endif
+#if TG_HAS(14)
+        if (sym && sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(plain, a, s);
+#endif
+#if TG_HAS(15)
         if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 1, false, 4, 4, false, 0, false>(single, a, s);
+#endif
     }
     *why = "horizon too long for the compiled kernel variants";
     return hipErrorInvalidValue;

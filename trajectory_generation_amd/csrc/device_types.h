@@ -28,6 +28,8 @@ struct StageDev {
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];
     int separate_xt;
+    int sm;                      // box rows kept as s = argument of the last projection (see admm_kernel)
+    int ql;                      // q of the position slots in LDS instead of registers
     int nwaves;                  // waves per workgroup the MFMA items are dealt to
     // MFMA work items (block group, row block) of every wave
     int wi_cnt[kAdmmWaves];
@@ -40,6 +42,16 @@ struct StageDev {
     int sb_rows;                 // LDS rows per block for C r: lr_crb * 16 + 8
     int lr_np;                   // partial sums C r is formed as: 1 (streamed form) or 4 (register-resident form)
     const double *DUfrag;
+    int lr_ukp;                  // k-steps of U per tile as stored in the wave streams (>= lr_uk, zero padded)
+    // Streamed variants: wave w reads the fragments of its items in the order of use from
+    // Wfrag + wave_off[w] * 64: every first-stage item (wi_*) as wi_nr ring rounds of kRingDepth
+    // k-steps starting at k-step wi_k0 (zero fragments past ks), then (low-rank form) 4 + lr_ukp
+    // fragments per tile (wj_*), then zero fragments for the ring to run out into.  In the low-rank
+    // form the k range of a row block of C is cut in two items whose results are partial sums
+    // wi_part = 0 / 1 of C r.
+    const double *Wfrag;
+    int wave_off[kAdmmWaves];
+    unsigned char wi_k0[kAdmmWaves][kMaxItems], wi_nr[kAdmmWaves][kMaxItems], wi_part[kAdmmWaves][kMaxItems];
     int wj_cnt[kAdmmWaves];
     unsigned char wj_grp[kAdmmWaves][kMaxItems], wj_rb[kAdmmWaves][kMaxItems];
     double dt, c2;               // c2 = dt^2/2 (position <- acceleration coupling, D = 3)

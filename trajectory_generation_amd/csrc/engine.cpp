@@ -80,7 +80,9 @@ struct DevStage {
     StageProblem sp;
     StageDev dev{};
     AsmDev adev{};
-    double *d_Mfrag = nullptr, *d_DUfrag = nullptr;
+    double *d_Mfrag = nullptr, *d_DUfrag = nullptr, *d_Wfrag = nullptr;
+    bool regs_dense = false;  // short horizon: the dense fragments fit the registers
+    int mfma_streamed = 0;    // MFMAs per tile-iteration of the streamed variants (zero-padding rounds included)
     int lowrank_mode = 0;     // 0: when it pays, 1: whenever the operators allow it, -1: never
     int *d_queue = nullptr;   // ticket counter of the kernel's instance queue
     int grid_cap = 0;
@@ -123,10 +125,13 @@ struct DevStage {
             const int stride = dev.nwaves * 64 / kTileDev, ncell = sp.nax * (mdl.N + 1);
             const int cells = (ncell + stride - 1) / stride;
             const bool in_registers = (six && cells <= 2 && dev.ks <= 16) || (!six && !xy && cells <= 1 && dev.ks <= 21);
+            regs_dense = in_registers;
             const int dense_mfma = dev.nrb * dev.ks, lr_mfma = sp.lr_crb * dev.ks + dev.nrb * (4 + sp.lr_uk);
             dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
             dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
-            dev.lr_np = 1;
+            // streamed low-rank form: C r as two partial sums (the k range of a row block of C is
+            // cut in two items, so that the first stage spreads evenly over the waves)
+            dev.lr_np = 2;
             // short 6-DOF horizons: the low-rank form with register-resident fragments and C r as
             // four partial sums (one first-stage item per wave)
             // (its B-operand reads run up to 64 rows past the start of the last block: they must
@@ -136,41 +141,117 @@ struct DevStage {
             if (lowrank_mode >= 0 && six && in_registers && sp.lr_q == 4 && sp.lr_crb == 1 && sp.lr_uk == 1 &&
                 (sp.n_int - sp.nb) + 64 <= rows_init) { dev.lr = 1; dev.lr_np = 4; }
         }
+        const bool streamed_lr = dev.lr && dev.lr_np == 2;
+        if (streamed_lr) {   // the second partial sum needs LDS of its own: dropped where the horizon leaves none
+            dev.separate_xt = 0; dev.sm = 0; dev.ql = 0;
+            if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.lr_np = 1;
+        }
+        // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
+        // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
+        // the iterates of the 16 instances still fit the 160 KiB of LDS
+        dev.separate_xt = streamed_lr ? 0 : 1;   // the streamed low-rank form writes xt over the rhs, tile by tile
+        dev.sm = 0; dev.ql = 0; dev.lr_ukp = 2;
+        if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.separate_xt = 0;
+        // 6-DOF: the boxes are the same for every instance and every call of the handle; when each
+        // contains zero the kernel keeps a box row's (z, y) as the one number they are projected from.
+        // Long horizons also move q of the position slots to LDS (five cells per thread: registers).
+        if (six) {
+            bool zero_inside = true;
+            for (int a = 0; a < sp.nax; a++)
+                for (int k = 0; k <= sp.D; k++) zero_inside = zero_inside && sp.lb[a][k] <= 0.0 && sp.ub[a][k] >= 0.0;
+            dev.sm = (zero_inside && dev.lr) ? 1 : 0;
+            if (dev.sm && streamed_lr) {
+                // the long-horizon variant is compiled with the s form, q in LDS and one k-step of
+                // U_I per tile (no input smoothing), or with none of them
+                const int sb_rows = dev.sb_rows;
+                dev.ql = 1;
+                if (dev.lr_uk == 1 && dev.lr_q == 4) { dev.lr_ukp = 1; dev.sb_rows = dev.lr_crb * 16; }   // no read past a tile's own four coefficients
+                if (dev.lr_ukp != 1 || admm_lds_bytes(dev) > (size_t)160 * 1024) { dev.ql = 0; dev.sm = 0; dev.lr_ukp = 2; dev.sb_rows = sb_rows; }
+            }
+        }
+        if (dev.lr && admm_lds_bytes(dev) > (size_t)160 * 1024) return fail(TG_E_ARG, "horizon too long: iterates do not fit the 160 KiB LDS");
         // deal the MFMA items: longest first onto the least loaded SIMD (waves w, w + 4, ... of a
         // workgroup share a SIMD), then onto its least loaded wave
-        struct Item { int grp, rb, cost; };
-        auto deal = [&](std::vector<Item> items, int *cnt, unsigned char (*grp)[kMaxItems], unsigned char (*rb)[kMaxItems]) -> bool {
+        struct Item { int grp, rb, cost, k0, nr, part; };
+        std::vector<Item> dealt1[kAdmmWaves], dealt2[kAdmmWaves];
+        auto deal = [&](std::vector<Item> items, std::vector<Item> *out) -> bool {
             std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
             int simd_load[4] = {0, 0, 0, 0}, wave_load[kAdmmWaves] = {0};
-            for (int w = 0; w < kAdmmWaves; w++) cnt[w] = 0;
             for (const Item &it : items) {
                 int sd = 0;
                 for (int k = 1; k < 4; k++) if (simd_load[k] < simd_load[sd]) sd = k;
                 int w = sd;
                 for (int c = sd + 4; c < dev.nwaves; c += 4) if (wave_load[c] < wave_load[w]) w = c;
-                if (cnt[w] >= kMaxItems) return false;
-                grp[w][cnt[w]] = (unsigned char)it.grp;
-                rb[w][cnt[w]] = (unsigned char)it.rb;
-                cnt[w]++;
+                if ((int)out[w].size() >= kMaxItems) return false;
+                out[w].push_back(it);
                 simd_load[sd] += it.cost; wave_load[w] += it.cost;
             }
             return true;
         };
+        const int PD = kRingDepth, rounds = (dev.ks + PD - 1) / PD;
         {
-            // dense: (group, row block); low-rank: (group, row block of the stacked C), then (group, tile)
+            // dense: (group, row block); low-rank: (group, row block of the stacked C[, part of the k
+            // range]), then (group, tile)
             std::vector<Item> items, tiles;
             for (int gi = 0; gi < dev.ngrp; gi++) {
+                const int cnt = dev.grp_cnt[gi];
                 if (dev.lr && dev.lr_np == 4) {   // (group, quarter of the k range)
-                    for (int pt = 0; pt < 4; pt++) items.push_back({gi, pt, dev.grp_cnt[gi] * 4});
+                    for (int pt = 0; pt < 4; pt++) items.push_back({gi, pt, cnt * 4, 0, 0, 0});
+                } else if (dev.lr) {
+                    const int ra = dev.lr_np == 2 ? (rounds + 1) / 2 : rounds, rb2 = rounds - ra;
+                    for (int rb = 0; rb < dev.lr_crb; rb++) {
+                        items.push_back({gi, rb, cnt * ra * PD, 0, ra, 0});
+                        if (rb2 > 0) items.push_back({gi, rb, cnt * rb2 * PD, ra * PD, rb2, 1});
+                    }
                 } else {
-                    for (int rb = 0; rb < (dev.lr ? dev.lr_crb : dev.nrb); rb++) items.push_back({gi, rb, dev.grp_cnt[gi] * dev.ks});
+                    for (int rb = 0; rb < dev.nrb; rb++) items.push_back({gi, rb, cnt * rounds * PD, 0, rounds, 0});
                 }
-                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, dev.grp_cnt[gi] * (4 + dev.lr_uk)});
+                for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, cnt * (4 + dev.lr_ukp), 0, 0, 0});
             }
-            if (!deal(items, dev.wi_cnt, dev.wi_grp, dev.wi_rb) || !deal(tiles, dev.wj_cnt, dev.wj_grp, dev.wj_rb))
+            if (!deal(items, dealt1) || !deal(tiles, dealt2))
                 return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
         }
-        if (dev.lr) {
+        mfma_streamed = 0;
+        for (int w = 0; w < kAdmmWaves; w++) {
+            dev.wi_cnt[w] = (int)dealt1[w].size(); dev.wj_cnt[w] = (int)dealt2[w].size();
+            for (size_t i = 0; i < dealt1[w].size(); i++) {
+                const Item &it = dealt1[w][i];
+                dev.wi_grp[w][i] = (unsigned char)it.grp; dev.wi_rb[w][i] = (unsigned char)it.rb;
+                dev.wi_k0[w][i] = (unsigned char)it.k0; dev.wi_nr[w][i] = (unsigned char)it.nr; dev.wi_part[w][i] = (unsigned char)it.part;
+                mfma_streamed += dev.grp_cnt[it.grp] * it.nr * PD;
+            }
+            for (size_t i = 0; i < dealt2[w].size(); i++) {
+                const Item &it = dealt2[w][i];
+                dev.wj_grp[w][i] = (unsigned char)it.grp; dev.wj_rb[w][i] = (unsigned char)it.rb;
+                mfma_streamed += dev.grp_cnt[it.grp] * (4 + dev.lr_ukp);
+            }
+        }
+        // fragment stream of every wave (streamed variants; the register-resident ones read Mfrag)
+        std::vector<double> W;
+        if (!(dev.lr && dev.lr_np == 4)) {
+            const std::vector<double> &src = dev.lr ? sp.Cfrag : sp.Mfrag;
+            const int rbs = dev.lr ? dev.lr_crb : dev.nrb;
+            const size_t ksa = (size_t)dev.ks_alloc;
+            const std::vector<double> zero(64, 0.0);
+            for (int w = 0; w < kAdmmWaves; w++) {
+                dev.wave_off[w] = (int)(W.size() / 64);
+                for (const Item &it : dealt1[w])
+                    for (int kk = it.k0; kk < it.k0 + it.nr * PD; kk++) {
+                        const double *f = kk < dev.ks ? &src[(((size_t)dev.grp_op[it.grp] * rbs + it.rb) * ksa + kk) * 64] : zero.data();
+                        W.insert(W.end(), f, f + 64);
+                    }
+                for (const Item &it : dealt2[w])
+                    for (int kk = 0; kk < 4 + dev.lr_ukp; kk++) {
+                        const double *f = kk < 4 + dev.lr_uk
+                            ? &sp.DUfrag[(((size_t)dev.grp_op[it.grp] * dev.nrb + it.rb) * (4 + dev.lr_uk) + kk) * 64] : zero.data();
+                        W.insert(W.end(), f, f + 64);
+                    }
+                for (int kk = 0; kk < kMaxItems * 6 + PD; kk++) W.insert(W.end(), zero.begin(), zero.end());   // the ring runs out into zeros
+            }
+            if ((rc = upload(W, &d_Wfrag))) return rc;
+        }
+        dev.Wfrag = d_Wfrag;
+        if (dev.lr && dev.lr_np == 4) {
             hipFree(d_Mfrag); d_Mfrag = nullptr;
             if ((rc = upload(sp.Cfrag, &d_Mfrag))) return rc;
             if ((rc = upload(sp.DUfrag, &d_DUfrag))) return rc;
@@ -195,11 +276,6 @@ struct DevStage {
             }
         }
         for (int k = 0; k < 6; k++) { dev.rho_mx[k] = sp.rho_mx[k]; dev.ub_mx[k] = sp.ub_mx[k]; }
-        // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
-        // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
-        // the iterates of the 16 instances still fit the 160 KiB of LDS
-        dev.separate_xt = (dev.lr && dev.lr_np == 1) ? 0 : 1;   // the streamed low-rank form writes xt over the rhs, tile by tile
-        if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.separate_xt = 0;
         dev.sigma = o.sigma; dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
         dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
         adev.n = sp.n; adev.m = sp.m; adev.rows_per_block = 32;
@@ -209,7 +285,7 @@ struct DevStage {
     }
     void release()
     {
-        hipFree(d_Mfrag); hipFree(d_DUfrag); hipFree(d_queue);
+        hipFree(d_Mfrag); hipFree(d_DUfrag); hipFree(d_Wfrag); hipFree(d_queue);
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
         hipFree(d_ovm); hipFree(d_warm); hipFree(d_res);
     }
@@ -217,8 +293,10 @@ struct DevStage {
     {
         int blocks = 0;
         for (int gi = 0; gi < dev.ngrp; gi++) blocks += dev.grp_cnt[gi];
-        const int per_block = dev.lr ? (dev.lr_np == 4 ? 16 : dev.lr_crb * dev.ks) + dev.nrb * (4 + dev.lr_uk) : dev.nrb * dev.ks;
-        if (mfma) *mfma = blocks * per_block;
+        int n = mfma_streamed;                                             // streamed: zero-padded ring rounds included
+        if (dev.lr && dev.lr_np == 4) n = blocks * (16 + dev.nrb * (4 + dev.lr_uk));   // register-resident low-rank form
+        else if (!dev.lr && regs_dense) n = blocks * dev.nrb * dev.ks;     // register-resident dense fragments
+        if (mfma) *mfma = n;
         if (lowrank) *lowrank = dev.lr;
     }
     size_t warm_rows() const

@@ -181,16 +181,18 @@ inline void column_space(const std::vector<long double> &R, int rows, int cols, 
 // Built-in multipliers of rho per class of box row (position, velocity, acceleration, input).
 // A uniform rho leaves a long iteration tail on instances whose position or input rows are
 // active (the 6-DOF altitude floor, saturated inputs): the step those rows need is set by the
-// state / input weights, not by their geometric mean.  Values picked from sweeps over 4096
-// random instances at N = 20 and N = 50 (tools/gpu_rho_sweep.py, tools/iter_need.py): they bring
-// the slowest 6-DOF instance from 375 (N = 20) / 825 (N = 50) iterations to 30 / 60 at eps 1e-3,
-// with 99.9 % (N = 20) of the instances done by iteration 25.  Longer horizons want a larger step
-// on the altitude floor rows (a violation builds up over more steps).
+// state / input weights, not by their geometric mean.  Values picked from sweeps over seeded
+// random instances at N = 20 and N = 50 (tools/gpu_rho_sweep.py, tools/iter_need.py, tools/rho_hist.py):
+// 6-DOF N = 20: slowest instance 375 -> 30 iterations at eps 1e-3, 99.9 % done at the first check
+// (iteration 25).  N = 50: (12, 3, 1, 4) passes the first check with 93.5 % of the instances, mean
+// 26.8 iterations, slowest of 8192 at 125-225 depending on the seed; a larger step on the altitude
+// floor rows, (20, 3, 1, 5), shortens the tail to 100 but only 73 % pass the first check (mean 31.8).
+// With the batch's instance slots refilled from a queue the mean sets the throughput.
 inline void default_rho_scale(const StageModel &mdl, double out[4])
 {
     if (mdl.family == TG_FAM_6DOF) {
         if (mdl.N <= 30) { out[0] = 15.0; out[1] = 1.0; out[2] = 1.0; out[3] = 3.0; }
-        else { out[0] = 20.0; out[1] = 3.0; out[2] = 1.0; out[3] = 5.0; }
+        else { out[0] = 12.0; out[1] = 3.0; out[2] = 1.0; out[3] = 4.0; }
     }
     else { out[0] = 1.0; out[1] = 10.0; out[2] = 3.0; out[3] = 3.0; }   // slowest XY / yaw instance 2466 / 297 -> 109 / 94
 }
