@@ -44,9 +44,15 @@ namespace tg {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// v_max_f64 / v_min_f64 issued as such: fmin / fmax first quieten every operand that comes from
+// memory (one more instruction per bound, 12 per cell and iteration where the box rows are kept
+// as s), which the hardware's IEEE maxNum / minNum does not need.
 __device__ __forceinline__ double clampd(double v, double lo, double hi)
 {
-    return fmin(fmax(v, lo), hi);
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(v), "v"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(r), "v"(hi));
+    return r;
 }
 
 // max over the four lanes that share an instance inside one wave (lane bits 4 and 5)
@@ -96,10 +102,13 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //        box contains zero (z = y = 0 at a cold start is then s = 0) and the boxes do not change
 //        between warm-started calls; the host checks both (not MIXED).
 // QL:    q of the cells' position slots lives in LDS (region QV) instead of registers.
+// SMJ:   step-major cells: a thread owns all NAX cells of its steps g, g + NT/16, ... (as the two-axis
+//        stage always does), so that the axis of a cell slot is known at compile time and the
+//        per-axis step sizes and bounds are scalar operands instead of LDS reads.
 // UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
 //        operator's own are zero).
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
-          bool SM = false, bool QL = false, int UK = 2>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -122,8 +131,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // The two-axis stage (XY) keeps both cells of a step in one thread (cc even: axis 0, odd: axis
     // 1): the linear solve works on their sum and difference (see the rhs phase), and the step's
     // mixed rows need both.
+    constexpr bool CAX = SMJ || MIXED;   // the axis of cell slot cc is cc % NAX
     auto cell_of = [&](int cc) __attribute__((always_inline)) -> int {
-        if (MIXED) { const int st = g + kStride * (cc >> 1); return st <= N ? (cc & 1) * N1 + st : ncell; }
+        if (CAX) { const int st = g + kStride * (cc / NAX); return st <= N ? (cc % NAX) * N1 + st : ncell; }
         const int c = g + kStride * cc;
         return c < ncell ? c : ncell;
     };
@@ -247,6 +257,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         }
     }
 
+    // per-axis constants of cell slot cc: scalar kernel arguments when the slot's axis is known at
+    // compile time, else the LDS table
+    auto crho = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.rho_box[cc % NAX][k] : lds[i_ct[cc] + k * 3]; };
+    auto clo = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.lb[cc % NAX][k] : lds[i_ct[cc] + k * 3 + 1]; };
+    auto chi = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.ub[cc % NAX][k] : lds[i_ct[cc] + k * 3 + 2]; };
     // Step sizes and box bounds of the thread's cells, in registers when few cells per thread leave
     // room: the LDS pipe is the busiest unit of the rhs and projection phases.  Slots 1.. have
     // symmetric bounds in every stage (the host checks); slot 0 keeps both ends (altitude floor).
@@ -257,8 +272,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
 #pragma unroll
-            for (int k = 0; k < S; k++) { c_rho[cc][k] = lds[i_ct[cc] + k * 3]; c_hi[cc][k] = lds[i_ct[cc] + k * 3 + 2]; }
-            c_lo0[cc] = lds[i_ct[cc] + 1];
+            for (int k = 0; k < S; k++) { c_rho[cc][k] = crho(cc, k); c_hi[cc][k] = chi(cc, k); }
+            c_lo0[cc] = clo(cc, 0);
         }
     }
 
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     auto box_of = [&](int cc, int k, double &lo, double &hi) __attribute__((always_inline)) {
         if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
         else if (REGC) { hi = c_hi[cc][k]; lo = k == 0 ? c_lo0[cc] : -hi; }
-        else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+        else { lo = clo(cc, k); hi = chi(cc, k); }
     };
     // SM: z and y/rho of a box row from s
     auto zy_of = [&](int cc, int k, double lo, double hi, double &zv, double &yv) __attribute__((always_inline)) {
@@ -302,8 +317,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
             for (int k = 0; k < D; k++) { zg0[k] = 0.0; yg[cc][k] = 0.0; b0[k] = 0.0; }
             if (MIXED) {
-                hiv[cc][0] = lds[i_ct[cc] + 1 * 3 + 2];
-                hiv[cc][1] = lds[i_ct[cc] + 2 * 3 + 2];
+                hiv[cc][0] = chi(cc, 1);
+                hiv[cc][1] = chi(cc, 2);
             }
             if (act && valid) {
                 qc = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
@@ -408,7 +423,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const int pstride = LR ? (n_int / nb) * P.sb_rows * 16 : 0;   // doubles between the partial sums of C r
     const int njt = (STREAM && LR) ? P.wj_cnt[wave] : 0;
     int s1_b[MAXIT], s1_o[MAXIT], s1_nr[MAXIT], s1_rows[MAXIT], s2_r[MAXIT], s2_s[MAXIT], s2_rows[MAXIT];
-    bool s1_two[MAXIT], s2_two[MAXIT];
+    // a wave's items of a stage are all pairs of blocks sharing an operator, or all single blocks
+    const bool s1_two_w = STREAM && PAIR && nit > 0 && P.grp_cnt[P.wi_grp[wave][0]] == 2;
+    const bool s2_two_w = STREAM && PAIR && njt > 0 && P.grp_cnt[P.wj_grp[wave][0]] == 2;
     if constexpr (STREAM) {
 #pragma unroll
         for (int it = 0; it < MAXIT; it++) {
@@ -416,7 +433,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             const int grp = in ? P.wi_grp[wave][it] : 0, rb = in ? P.wi_rb[wave][it] : 0;
             const int k0 = in ? P.wi_k0[wave][it] : 0, part = in ? P.wi_part[wave][it] : 0;
             const int blk = P.grp_first[grp];
-            s1_two[it] = PAIR && P.grp_cnt[grp] == 2;
             s1_nr[it] = in ? P.wi_nr[wave][it] : 0;
             s1_b[it] = V0 + (blk * nb + 4 * k0) * 16;
             s1_o[it] = LR ? SB + part * pstride + (blk * P.sb_rows + rb * 16) * 16 : VX + (blk * nb + rb * 16) * 16;
@@ -427,7 +443,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             const bool in = jt < njt;
             const int grp = in ? P.wj_grp[wave][jt] : 0, I = in ? P.wj_rb[wave][jt] : 0;
             const int blk = P.grp_first[grp];
-            s2_two[jt] = PAIR && P.grp_cnt[grp] == 2;
             s2_r[jt] = V0 + (blk * nb + I * 16) * 16;
             s2_s[jt] = SB + (blk * P.sb_rows + I * P.lr_q) * 16;
             s2_rows[jt] = nb - I * 16;
@@ -461,10 +476,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #else
         STAMP(0);
 #endif
-        if constexpr (STREAM) {   // the ring's first fragments travel while the rhs is formed
-#pragma unroll
-            for (int p = 0; p < PD; p++) af[p] = ws[ulane + p * 64];
-        }
         // -------------------------------------------------------- rhs = sigma x - q + A'(rho z - y)
         // Cells are handled in groups of G: every LDS read of the group is issued before its first
         // LDS write.  The compiler cannot tell that the regions do not overlap, so a write between
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if constexpr (G > 1 || SM) {
 #pragma unroll
                     for (int k = 0; k < S; k++) {
-                        rr[j][k] = REGC ? c_rho[cc][k] : lds[i_ct[cc] + k * 3];
+                        rr[j][k] = REGC ? c_rho[cc][k] : crho(cc, k);
                         if constexpr (SM) box_of(cc, k, bx[j][k][0], bx[j][k][1]);
                     }
                 }
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 for (int l = 0; l < D; l++) {
                     double zv, yv;
                     zy_of(cc, l, SM ? bx[j][l][0] : 0.0, SM ? bx[j][l][1] : 0.0, zv, yv);
-                    double acc = __builtin_fma((G > 1 || SM) ? rr[j][l] : lds[i_ct[cc] + l * 3], zv - yv, sigma * x[cc][l]) - wo[j][l];
+                    double acc = __builtin_fma((G > 1 || SM) ? rr[j][l] : crho(cc, l), zv - yv, sigma * x[cc][l]) - wo[j][l];
                     if (l == 0) acc -= qv[j];
 #pragma unroll
                     for (int k = 0; k <= l; k++) acc = __builtin_fma(chain_coef<D>(k, l, dt, c2), wn[j][k], acc);
@@ -522,7 +533,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 // input slot; at step N it is a padding variable whose x, z, y and neighbours stay zero
                 double zvD, yvD;
                 zy_of(cc, D, SM ? bx[j][D][0] : 0.0, SM ? bx[j][D][1] : 0.0, zvD, yvD);
-                racc[j][D] = __builtin_fma((G > 1 || SM) ? rr[j][D] : lds[i_ct[cc] + D * 3], zvD - yvD, __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
+                racc[j][D] = __builtin_fma((G > 1 || SM) ? rr[j][D] : crho(cc, D), zvD - yvD, __builtin_fma(dt, wn[j][D - 1], sigma * x[cc][D]));
             }
             if constexpr (MIXED) {
                 // The two axes are interchangeable in K = P + sigma I + A' rho A (same weights, same
@@ -545,6 +556,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             }
         }
         STAMP(1);
+        if constexpr (STREAM) {   // the ring's first fragments travel while the waves gather at the barrier
+#pragma unroll
+            for (int p = 0; p < PD; p++) af[p] = ws[ulane + p * 64];
+        }
         __syncthreads();
         STAMP(2);
         // -------------------------------------------------------- xt = Kinv * rhs  (MFMA)
@@ -638,16 +653,16 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             const double *wp = ws + PD * 64;
             const int nb16 = nb * 16, sb16 = P.sb_rows * 16;
             const bool np2 = P.lr_np == 2;
+            // a wave's items are all pairs of blocks or all single blocks (the host deals them so)
+            auto stage1 = [&](auto two_c) __attribute__((always_inline)) {
+                constexpr bool TWO = decltype(two_c)::value;
 #pragma unroll
-            for (int it = 0; it < MAXIT; it++) {
-                if (it < nit) {
-                    const double *b0 = lds + uniform_off(s1_b[it]) + laneoff;
-                    auto run = [&](auto two_c) __attribute__((always_inline)) {
-                        constexpr bool TWO = decltype(two_c)::value;
+                for (int it = 0; it < MAXIT; it++) {
+                    if (it < nit) {
+                        const double *b = lds + uniform_off(s1_b[it]) + laneoff;
                         // two independent accumulation chains either way: a dependent MFMA issues
                         // every 128 clocks, two alternating chains every 64
                         d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
-                        const double *b = b0;
                         for (int r = 0; r < s1_nr[it]; r++) {
 #pragma unroll
                             for (int p = 0; p < PD; p++) {
@@ -674,21 +689,21 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                             for (int r = 0; r < 4; r++) o0[sb16 + r * 64] = c1[r];
                         }
-                    };
-                    if (PAIR && s1_two[it]) run(std::true_type{}); else run(std::false_type{});
+                    }
                 }
-            }
+            };
+            if (PAIR && s1_two_w) stage1(std::true_type{}); else stage1(std::false_type{});
             STAMP(3);
             __syncthreads();
             STAMP(4);
             // wp now points at fragment PD of the second stage: fragment j + PD is wp[j * 64]
+            auto stage2 = [&](auto two_c) __attribute__((always_inline)) {
+                constexpr bool TWO = decltype(two_c)::value;
 #pragma unroll
-            for (int jt = 0; jt < MAXIT; jt++) {
-                if (jt < njt) {
-                    double *r0p = lds + uniform_off(s2_r[jt]) + laneoff;
-                    const double *s0p = lds + uniform_off(s2_s[jt]) + laneoff;
-                    auto run = [&](auto two_c) __attribute__((always_inline)) {
-                        constexpr bool TWO = decltype(two_c)::value;
+                for (int jt = 0; jt < MAXIT; jt++) {
+                    if (jt < njt) {
+                        double *r0p = lds + uniform_off(s2_r[jt]) + laneoff;
+                        const double *s0p = lds + uniform_off(s2_s[jt]) + laneoff;
                         double bf0[KD], bf1[TWO ? KD : 1];
 #pragma unroll
                         for (int kk = 0; kk < 4; kk++) {
@@ -717,30 +732,48 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                             for (int r = 0; r < 4; r++) c0[r] += c1[r];
                         }
-                        const int rows = s2_rows[jt] - (lane >> 4);   // rows past the block are MFMA padding
+                        if (s2_rows[jt] >= 16) {                      // a whole tile (all but the block's last)
 #pragma unroll
-                        for (int r = 0; r < 4; r++) if (4 * r < rows) r0p[r * 64] = c0[r];
-                        if constexpr (TWO) {
+                            for (int r = 0; r < 4; r++) r0p[r * 64] = c0[r];
+                            if constexpr (TWO) {
 #pragma unroll
-                            for (int r = 0; r < 4; r++) if (4 * r < rows) r0p[nb16 + r * 64] = c1[r];
+                                for (int r = 0; r < 4; r++) r0p[nb16 + r * 64] = c1[r];
+                            }
+                        } else {
+                            const int rows = s2_rows[jt] - (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                            for (int r = 0; r < 4; r++) if (4 * r < rows) r0p[r * 64] = c0[r];
+                            if constexpr (TWO) {
+#pragma unroll
+                                for (int r = 0; r < 4; r++) if (4 * r < rows) r0p[nb16 + r * 64] = c1[r];
+                            }
                         }
-                    };
-                    if (PAIR && s2_two[jt]) run(std::true_type{}); else run(std::false_type{});
+                    }
                 }
-            }
+            };
+            if (PAIR && s2_two_w) stage2(std::true_type{}); else stage2(std::false_type{});
         } else
         {
             // with a separate xt vector (SEP) an item's rows are stored as soon as they are done;
             // otherwise xt overwrites the rhs and the stores wait for every wave's last read
             auto store = [&](int ooff, int rows_left, bool two, const d4 &c0, const d4 &c1) __attribute__((always_inline)) {
                 double *o0 = lds + uniform_off(ooff) + laneoff;
-                const int rows = rows_left - (lane >> 4);   // rows past the block are MFMA padding
+                double *o1 = o0 + (size_t)nb * 16;
+                if (rows_left >= 16) {                        // a whole row block (all but the block's last)
 #pragma unroll
-                for (int r = 0; r < 4; r++) if (4 * r < rows) o0[r * 64] = c0[r];
-                if (PAIR && two) {
-                    double *o1 = o0 + (size_t)nb * 16;
+                    for (int r = 0; r < 4; r++) o0[r * 64] = c0[r];
+                    if (PAIR && two) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) if (4 * r < rows) o1[r * 64] = c1[r];
+                        for (int r = 0; r < 4; r++) o1[r * 64] = c1[r];
+                    }
+                } else {
+                    const int rows = rows_left - (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (4 * r < rows) o0[r * 64] = c0[r];
+                    if (PAIR && two) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (4 * r < rows) o1[r * 64] = c1[r];
+                    }
                 }
             };
             d4 acc0[SEP ? 1 : MAXIT], acc1[(PAIR && !SEP) ? MAXIT : 1];
@@ -790,14 +823,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 // and its first PD fragments were requested at the top of the iteration
                 const double *wp = ws + PD * 64;
                 const int nb16 = nb * 16;
+                auto stage1 = [&](auto two_c) __attribute__((always_inline)) {
+                    constexpr bool TWO = decltype(two_c)::value;
 #pragma unroll
-                for (int it = 0; it < MAXIT; it++) {
-                    if (it < nit) {
-                        const double *b0 = lds + uniform_off(s1_b[it]) + laneoff;
-                        auto run = [&](auto two_c) __attribute__((always_inline)) {
-                            constexpr bool TWO = decltype(two_c)::value;
+                    for (int it = 0; it < MAXIT; it++) {
+                        if (it < nit) {
+                            const double *b = lds + uniform_off(s1_b[it]) + laneoff;
                             d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
-                            const double *b = b0;
                             for (int r = 0; r < s1_nr[it]; r++) {
 #pragma unroll
                                 for (int p = 0; p < PD; p++) {
@@ -820,10 +852,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             }
                             if constexpr (SEP) store(s1_o[it], s1_rows[it], TWO, c0, c1);
                             else { acc0[it] = c0; if constexpr (PAIR) acc1[it] = c1; }
-                        };
-                        if (PAIR && s1_two[it]) run(std::true_type{}); else run(std::false_type{});
+                        }
                     }
-                }
+                };
+                if (PAIR && s1_two_w) stage1(std::true_type{}); else stage1(std::false_type{});
             }
             if constexpr (!SEP) {
                 __syncthreads();
@@ -831,7 +863,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 for (int it = 0; it < MAXIT; it++) {
                     if (it < nit) {
                         if constexpr (KSREG > 0) store(VX + P.grp_first[grp_r] * nb * 16 + rb_r * 256, nb - rb_r * 16, two_r, acc0[it], acc1[PAIR ? it : 0]);
-                        else store(s1_o[it], s1_rows[it], s1_two[it], acc0[it], acc1[PAIR ? it : 0]);
+                        else store(s1_o[it], s1_rows[it], s1_two_w, acc0[it], acc1[PAIR ? it : 0]);
                     }
                 }
             }
@@ -851,15 +883,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     if (cc >= MAXC) continue;
                     const double *xin = vx + i_var[cc];
                     const double *xpr = lds + i_prev[cc];
-                    const double *ct = lds + i_ct[cc];
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         xt[j][k] = xin[k * 16]; xp[j][k] = xpr[k * 16];
                         if constexpr (G > 1) {
                             if (MIXED && (k == 1 || k == 2)) { bnd[j][k][1] = hiv[cc][k - 1]; bnd[j][k][0] = -bnd[j][k][1]; }
                             else if (REGC) { bnd[j][k][1] = c_hi[cc][k]; bnd[j][k][0] = k == 0 ? c_lo0[cc] : -c_hi[cc][k]; }
-                            else { bnd[j][k][0] = ct[k * 3 + 1]; bnd[j][k][1] = ct[k * 3 + 2]; }
-                            if constexpr (CHK) rr[j][k] = REGC ? c_rho[cc][k] : ct[k * 3];
+                            else { bnd[j][k][0] = clo(cc, k); bnd[j][k][1] = chi(cc, k); }
+                            if constexpr (CHK) rr[j][k] = REGC ? c_rho[cc][k] : crho(cc, k);
                         }
                     }
                     if constexpr (G > 1) {
@@ -888,14 +919,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         double lo, hi;   // a single cell at a time reads its constants where they are used
                         if constexpr (G > 1) { lo = bnd[j][k][0]; hi = bnd[j][k][1]; }
                         else if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
-                        else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+                        else { lo = clo(cc, k); hi = chi(cc, k); }
                         double zo, yo;
                         zy_of(cc, k, lo, hi, zo, yo);
                         const double zr = __builtin_fma(alpha, xt[j][k], oma * zo);
                         const double s = zr + yo;
                         const double zn = clampd(s, lo, hi);
                         if constexpr (CHK) {
-                            double d = (G > 1 ? rr[j][k] : lds[i_ct[cc] + k * 3]) * (zr - zn);
+                            double d = (G > 1 ? rr[j][k] : crho(cc, k)) * (zr - zn);
                             if (hi > kInfBound) d = lo < -kInfBound ? 0.0 : fmin(d, 0.0);
                             else if (lo < -kInfBound) d = fmax(d, 0.0);
                             pin_n = fmax(pin_n, fabs(d));
@@ -1047,7 +1078,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     const int ax = c / N1, st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
                     const double *xpr = lds + i_prev[cc];
-                    const double *ct = lds + i_ct[cc];
                     double pdiag = 0.0;
 #pragma unroll
                     for (int k = 0; k < NAX; k++) if (ax == k) pdiag = P.pdiag[k];
@@ -1072,7 +1102,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int l = 0; l < D; l++) {
                         const double px = l == 0 ? pdiag * x[cc][0] : 0.0;
-                        double aty = ct[l * 3] * yc[l] - rho_eq * yg[cc][l];
+                        double aty = crho(cc, l) * yc[l] - rho_eq * yg[cc][l];
 #pragma unroll
                         for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
                         if (MIXED && l >= 1) aty += mixc[l];
@@ -1088,7 +1118,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             const double up = st < N - 1 ? xin[(D + S) * 16] : x[cc][D];
                             px += P.smooth * ((x[cc][D] - um) + (x[cc][D] - up));
                         }
-                        const double aty = ct[D * 3] * yc[D] + dt * yn[D - 1];
+                        const double aty = crho(cc, D) * yc[D] + dt * yn[D - 1];
                         m_rd = fmax(m_rd, fabs(px + aty));
                         m_px = fmax(m_px, fabs(px));
                         m_aty = fmax(m_aty, fabs(aty));
@@ -1456,10 +1486,10 @@ size_t admm_lds_bytes(const StageDev &P)
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
-          bool SM = false, bool QL = false, int UK = 2>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ>;
     if ((P.sm != 0) != SM || (P.ql != 0) != QL) return hipErrorInvalidValue;   // the LDS layout follows P.ql
     if (KSREG == 0 && (!P.Wfrag || (LR && (P.lr_np > 2 || P.lr_ukp != UK)))) return hipErrorInvalidValue;
     const size_t lds_bytes = admm_lds_bytes(P);
@@ -1567,6 +1597,8 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
         const int items = needi > needj ? needi : needj;
         if (P.D == 2 && P.nax == 3 && !P.mixed && needc <= 5 && items <= 3) {
 #if TG_HAS(2)
+            // (step-major cells, SMJ with MAXC = 6, were measured at N = 50: 20350 against 20000 cycles
+            // per iteration -- the per-axis constants then travel through spilled scalar registers)
             if (P.sm && P.ql && P.lr_ukp == 1) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s);
 #endif
 #if TG_HAS(3)

@@ -174,18 +174,48 @@ struct DevStage {
         // workgroup share a SIMD), then onto its least loaded wave
         struct Item { int grp, rb, cost, k0, nr, part; };
         std::vector<Item> dealt1[kAdmmWaves], dealt2[kAdmmWaves];
-        auto deal = [&](std::vector<Item> items, std::vector<Item> *out) -> bool {
-            std::stable_sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
-            int simd_load[4] = {0, 0, 0, 0}, wave_load[kAdmmWaves] = {0};
-            for (const Item &it : items) {
-                int sd = 0;
-                for (int k = 1; k < 4; k++) if (simd_load[k] < simd_load[sd]) sd = k;
-                int w = sd;
-                for (int c = sd + 4; c < dev.nwaves; c += 4) if (wave_load[c] < wave_load[w]) w = c;
-                if ((int)out[w].size() >= kMaxItems) return false;
-                out[w].push_back(it);
-                simd_load[sd] += it.cost; wave_load[w] += it.cost;
+        // A wave's items of one stage are all pairs of blocks that share an operator or all single
+        // blocks (the kernel then runs one code path per wave and stage).  For every split of the
+        // eight waves into pair waves and single waves the items go longest first onto the least
+        // loaded wave of their kind; the waves are then matched to SIMDs heaviest with lightest
+        // (waves w and w + 4 share SIMD w % 4); the split with the lightest heaviest SIMD wins.
+        auto deal = [&](const std::vector<Item> &items, std::vector<Item> *out) -> bool {
+            std::vector<Item> kind[2];
+            for (const Item &it : items) kind[dev.grp_cnt[it.grp] == 2 ? 1 : 0].push_back(it);
+            for (auto &v : kind) std::stable_sort(v.begin(), v.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
+            long best = -1;
+            std::vector<Item> best_bins[kAdmmWaves];
+            for (int npw = 0; npw <= kAdmmWaves; npw++) {
+                if ((npw == 0) != kind[1].empty() || (npw == kAdmmWaves) != kind[0].empty()) {
+                    if (!(kind[0].empty() && kind[1].empty())) continue;
+                }
+                std::vector<Item> bins[kAdmmWaves];
+                int load[kAdmmWaves] = {0};
+                bool ok = true;
+                for (int k = 0; k < 2 && ok; k++) {
+                    const int lo = k == 1 ? 0 : npw, hi = k == 1 ? npw : kAdmmWaves;
+                    for (const Item &it : kind[k]) {
+                        int w = lo;
+                        for (int c = lo + 1; c < hi; c++) if (load[c] < load[w]) w = c;
+                        if ((int)bins[w].size() >= kMaxItems) { ok = false; break; }
+                        bins[w].push_back(it); load[w] += it.cost;
+                    }
+                }
+                if (!ok) continue;
+                int order[kAdmmWaves];
+                std::iota(order, order + kAdmmWaves, 0);
+                std::stable_sort(order, order + kAdmmWaves, [&](int x, int y) { return load[x] > load[y]; });
+                long worst = 0, most = 0;
+                for (int k = 0; k < 4; k++) worst = std::max<long>(worst, load[order[k]] + load[order[7 - k]]);
+                for (int w = 0; w < kAdmmWaves; w++) most = std::max<long>(most, (long)bins[w].size());
+                const long score = worst * 16 + most;
+                if (best < 0 || score < best) {
+                    best = score;
+                    for (int k = 0; k < 4; k++) { best_bins[k] = bins[order[k]]; best_bins[k + 4] = bins[order[7 - k]]; }
+                }
             }
+            if (best < 0) return false;
+            for (int w = 0; w < kAdmmWaves; w++) out[w] = best_bins[w];
             return true;
         };
         const int PD = kRingDepth, rounds = (dev.ks + PD - 1) / PD;
