@@ -131,6 +131,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // The two-axis stage (XY) keeps both cells of a step in one thread (cc even: axis 0, odd: axis
     // 1): the linear solve works on their sum and difference (see the rhs phase), and the step's
     // mixed rows need both.
+    // axis of cell c: comparisons instead of a division by the run-time N + 1
+    auto axis_of = [&](int c) __attribute__((always_inline)) -> int {
+        int ax = 0;
+#pragma unroll
+        for (int k = 1; k < NAX; k++) ax += c >= k * N1 ? 1 : 0;
+        return ax;
+    };
     constexpr bool CAX = SMJ || MIXED;   // the axis of cell slot cc is cc % NAX
     auto cell_of = [&](int cc) __attribute__((always_inline)) -> int {
         if (CAX) { const int st = g + kStride * (cc / NAX); return st <= N ? (cc % NAX) * N1 + st : ncell; }
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     for (int cc = 0; cc < MAXC; cc++) {
         const int c = cell_of(cc);
         const bool act = c < ncell;
-        const int ax = act ? c / N1 : 0;
+        const int ax = act ? axis_of(c) : 0;
         const int st = act ? c - ax * N1 : 0;
         int abase = 0;
 #pragma unroll
@@ -299,11 +306,25 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         const bool valid = fresh && inst < a.B && !gated;
         double qmax = 0.0;
         if (!fresh) return qmax;
+        // the reference entries of all the thread's cells are requested before the first is used
+        // (a slot's instance sits anywhere in the batch: every one of these reads is a cache miss)
+        double refv[MAXC];
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
             const int c = cell_of(cc);
             const bool act = c < ncell;
-            const int ax = act ? c / N1 : 0;
+            const int ax = act ? axis_of(c) : 0;
+            const int st = act ? c - ax * N1 : 0;
+            int refoff = 0;
+#pragma unroll
+            for (int k = 0; k < NAX; k++) if (ax == k) refoff = P.ref_off[k];
+            refv[cc] = a.ref[(act && valid) ? (size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst : (size_t)0];
+        }
+#pragma unroll
+        for (int cc = 0; cc < MAXC; cc++) {
+            const int c = cell_of(cc);
+            const bool act = c < ncell;
+            const int ax = act ? axis_of(c) : 0;
             const int st = act ? c - ax * N1 : 0;
             int abase = 0, x0r = 0, refoff = 0;
             double qw = 0.0;
@@ -321,7 +342,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 hiv[cc][1] = chi(cc, 2);
             }
             if (act && valid) {
-                qc = qw * a.ref[(size_t)(st * P.ref_stride + refoff) * a.ref_ld + inst];
+                qc = qw * refv[cc];
                 qmax = fmax(qmax, fabs(qc));
                 if (st == 0) {
 #pragma unroll
@@ -463,6 +484,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     double pin_n = 0.0, pin_l = 0.0;
 #ifdef TG_STAMP
     long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
+    long long chk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, chk_last = 0;   // sections of a termination check; [7] counts them
+#define CSTAMP(i) do { __builtin_amdgcn_s_waitcnt(0); const long long now__ = (long long)__builtin_amdgcn_s_memtime(); \
+                       if ((i) > 0) chk_acc[(i) - 1] += now__ - chk_last; chk_last = now__; } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
 #endif
     auto step = [&](auto chk_c) __attribute__((always_inline)) {
         // The iterates must not depend on whether this is a checking iteration (a slot meets them
@@ -1019,6 +1045,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         const bool sfull = full && (fine <= 0 || local % check == 0 || last);
         // -------------------------------------------------------- termination check
         {
+            CSTAMP(0);
             __syncthreads();
             // ||A' delta_y||_inf: own part + the next step's dynamics rows + the mixed rows
             double m_atdy = 0.0;
@@ -1070,12 +1097,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
             }
             __syncthreads();
+            CSTAMP(1);
             double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
                 const int c = cell_of(cc);
                 if (c < ncell) {
-                    const int ax = c / N1, st = c - ax * N1;
+                    const int ax = axis_of(c), st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
                     const double *xpr = lds + i_prev[cc];
                     double pdiag = 0.0;
@@ -1163,6 +1191,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                 }
             }
+            CSTAMP(2);
             m_rp = wave_gmax(m_rp); m_ax = wave_gmax(m_ax); m_z = wave_gmax(m_z);
             m_rd = wave_gmax(m_rd); m_px = wave_gmax(m_px); m_aty = wave_gmax(m_aty);
             pin_n = wave_gmax(pin_n); m_atdy = wave_gmax(m_atdy);
@@ -1196,19 +1225,25 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // recession cone of [l, u], separates the constraint set from the range of A
             const bool pinf = sfull && eligible && !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
                               pin_l < -eps_pinf * pin_n && m_atdy < eps_pinf * pin_n;
+            CSTAMP(3);
             if (!done && (conv || pinf || last)) {
                 done = true;
                 const int inst = slot_inst[t];
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
                 // is written for an infeasible instance
-                for (int cc = 0; cc < (conv || !pinf ? MAXC : 0); cc++) {
+                const bool wr = conv || !pinf;
+#pragma unroll
+                for (int cc = 0; cc < MAXC; cc++) {
                     const int c = cell_of(cc);
-                    if (c < ncell) {
-                        const int ax = c / N1, st = c - ax * N1;
-                        const double *xs = vx + (size_t)(P.axis_base[ax] + st * S) * 16 + t;
+                    if (wr && c < ncell) {
+                        const int ax = axis_of(c), st = c - ax * N1;
+                        int xoff = 0, uoff = 0;
+#pragma unroll
+                        for (int k = 0; k < NAX; k++) if (ax == k) { xoff = P.X_off[k]; uoff = P.U_off[k]; }
+#pragma unroll
                         for (int k = 0; k < D; k++)
-                            a.X[(size_t)(st * P.X_stride + P.X_off[ax] + k * P.X_slot) * a.ld + inst] = xs[k * 16];
-                        if (st < N) a.U[(size_t)(st * P.U_stride + P.U_off[ax]) * a.ld + inst] = xs[D * 16];
+                            a.X[(size_t)(st * P.X_stride + xoff + k * P.X_slot) * a.ld + inst] = x[cc][k];
+                        if (st < N) a.U[(size_t)(st * P.U_stride + uoff) * a.ld + inst] = x[cc][D];
                     }
                 }
                 if (g == 0) {
@@ -1221,7 +1256,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     for (int cc = 0; cc < MAXC; cc++) {
                         const int c = cell_of(cc);
                         if (c < ncell) {
-                            const int ax = c / N1, st = c - ax * N1;
+                            const int ax = axis_of(c), st = c - ax * N1;
                             int abase = 0;
 #pragma unroll
                             for (int k = 0; k < NAX; k++) if (ax == k) abase = P.axis_base[k];
@@ -1255,6 +1290,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                 }
             }
+            CSTAMP(4);
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
@@ -1271,14 +1307,24 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     for (int k = 0; k < 6; k++) lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zm[mm][k] - ym[mm][k]);
                 }
             }
+            CSTAMP(5);
             // slots whose instance has terminated take the next unassigned one
             const bool need = done && !exhausted;
             if (__syncthreads_or(need ? 1 : 0)) {
+                // one ticket draw per workgroup: the slots that need an instance take consecutive
+                // ones in slot order, so that their reads and writes of the batch arrays (instance
+                // minor) fall into the same cache lines
                 int *next = (int *)rsum;
-                if (need && g == 0) {
-                    const int ni = a.queue_base + atomicAdd(a.queue, 1);
-                    next[t] = ni < a.B ? ni : -1;
-                    red[6 * 16 + t] = 0ull;
+                if (wave == 0) {
+                    const unsigned long long mask = __ballot(need && g == 0);
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(a.queue, (int)__popcll(mask));
+                    base = __shfl(base, 0);
+                    if (need && g == 0) {
+                        const int ni = a.queue_base + base + (int)__popcll(mask & ((1ull << t) - 1ull));
+                        next[t] = ni < a.B ? ni : -1;
+                        red[6 * 16 + t] = 0ull;
+                    }
                 }
                 __syncthreads();
                 bool fresh = false;
@@ -1297,12 +1343,18 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     __syncthreads();
                 }
             }
+#ifdef TG_STAMP
+            CSTAMP(6);
+            chk_acc[7] += 1;
+            stamp_last = chk_last;     // the check is not part of the next iteration's first section
+#endif
             if (__syncthreads_and((done && exhausted) ? 1 : 0)) break;
         }
     }
 #ifdef TG_STAMP
-    if (blockIdx.x == 0 && lane == 0)
-        for (int i = 0; i < 8; i++) a.U[wave * 8 + i] = (double)stamp_acc[i];
+    // waves 0 and 4 (the two waves of SIMD 0) of workgroup 0: columns 0..15 of row 0 belong to its own instances
+    if (blockIdx.x == 0 && lane == 0 && (wave & 3) == 0)
+        for (int i = 0; i < 8; i++) { a.U[(wave >> 2) * 8 + i] = (double)stamp_acc[i]; a.X[(wave >> 2) * 8 + i] = (double)chk_acc[i]; }
 #endif
 }
 
