@@ -41,6 +41,7 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "mpc_6dof_B262144_N50"
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD at 2.4 GHz)
 FP64_MFMA_SUSTAINED_TFLOPS = 75.7   # tools/microbench/mfma_valu_overlap.hip on the box: register-only MFMA, two chains per SIMD
+PIPELINE = {"mpc_12state_B4096_N20": 8, "mpc_6dof_B4096_N20": 2}   # default batches in flight (--pipeline 0)
 MIN_TIMED_S = 0.5              # shorter regions are repeated until this much has been timed
 PROFILE_ROUND = "r02"
 
@@ -188,6 +189,9 @@ def main():
                     help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
     ap.add_argument("--smoothing", action="store_true", help="input smoothing term on (the test mains' setting; config/mpc.yaml has it off)")
     ap.add_argument("--stress", action="store_true", help="every instance in the geometry of the reference's test main: target 40 m above, limits active")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="batches in flight: consecutive steps go round-robin to this many handles, each with its own "
+                         "buffers and HIP stream (0: the workload's default; 1: one handle, steps strictly in turn)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -218,13 +222,26 @@ def main():
         first, B = rank * count, count                     # fixed per GPU: every rank owns its own slab
     opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check,
                         check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank)
-    if model == "6dof":
-        eng = tg.BatchedMPC6(tg.mpc6_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
-        gen = synth.mpc6
-    else:
-        eng = tg.BatchedMPC12(tg.mpc12_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
-        gen = synth.mpc12
-    buf = eng.alloc(B)
+    closed = args.workload.startswith("rollout")
+    # A batch that is one wave of workgroups (B = 4096: 256 tiles on 256 CUs) ends with the chip
+    # waiting for its slowest tile; a server keeps the next batches in flight meanwhile.  Steps go
+    # round-robin to `depth` handles, each with its own buffers and stream.  The per-batch latency
+    # is measured separately with one batch in flight.
+    depth = args.pipeline if args.pipeline > 0 else (1 if closed else PIPELINE.get(args.workload, 1))
+    if closed and depth > 1:
+        sys.exit("--pipeline > 1 is for the open-loop workloads (a closed-loop step depends on the one before)")
+
+    def make_engine():
+        if model == "6dof":
+            return tg.BatchedMPC6(tg.mpc6_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
+        return tg.BatchedMPC12(tg.mpc12_params(N=N, enable_control_smoothing=args.smoothing), opts, device=local)
+
+    gen = synth.mpc6 if model == "6dof" else synth.mpc12
+    engs = [make_engine() for _ in range(depth)]
+    eng = engs[0]
+    bufs = [e.alloc(B) for e in engs]
+    buf = bufs[0]
+    streams = [torch.cuda.Stream(device=local) for _ in range(depth)] if depth > 1 else [None]
     for a in range(0, B, 32768):                           # generated and uploaded in slabs
         b = min(a + 32768, B)
         x0, ref = gen(SEED + seed_off, N, 0.1, b - a, first + a)
@@ -232,18 +249,20 @@ def main():
             x0, ref = synth.stress(model, x0, ref, N)
         buf["x0"][:, a:b] = torch.from_numpy(np.ascontiguousarray(x0.T)).cuda()
         buf["ref"][:, a:b] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()
+    for other in bufs[1:]:
+        other["x0"].copy_(buf["x0"]); other["ref"].copy_(buf["ref"])
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    closed = args.workload.startswith("rollout")
-
-    def step():
+    def step(i=0):
         if closed:
             eng.solve(buf, warm=True)
             eng.plant_step(buf)
             eng.ref_shift(buf)
+        elif depth > 1:
+            engs[i % depth].solve(bufs[i % depth], stream=streams[i % depth])
         else:
             eng.solve(buf)
 
@@ -254,8 +273,8 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
-        for _ in range(k):
-            step()
+        for i in range(k):
+            step(i)
         ev1.record()
         torch.cuda.synchronize(); barrier()
         el = time.perf_counter() - t0
@@ -265,8 +284,8 @@ def main():
             el = float(t.item())
         return el, ev0.elapsed_time(ev1)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(max(args.warmup, depth if depth > 1 else 0)):
+        step(i)
     # exactly --steps steps per timed region; a region shorter than MIN_TIMED_S is repeated (every
     # rank derives the same count from the reduced time of the first one)
     el, ev = region(args.steps)
@@ -338,6 +357,10 @@ def main():
     # step -- xy bounds, yaw reference, plant, shift -- are < 1 % of it); the per-launch event pairs
     # taken after the timed regions are reported beside it
     avg_kernel_ms = region_ms / (timed_steps * launches_per_step)
+    if depth > 1:
+        # launches of different handles overlap: the wall time of the region per launch (what one
+        # launch costs the device), not the duration of a launch
+        avg_kernel_ms = elapsed * 1e3 / (timed_steps * launches_per_step)
     per_launch_event_ms = kern_ms / max(kern_launches, 1)
     tflops = lambda f: f / (avg_kernel_ms * 1e-3) / 1e12 if avg_kernel_ms > 0 else 0.0
     achieved = tflops(executed)
@@ -361,9 +384,10 @@ def main():
                    "check_fine": args.check_fine, "grid_cap": args.grid_cap, "lowrank": args.lowrank,
                    "smoothing": bool(args.smoothing), "inputs": "stress" if args.stress else "seeded",
                    "rho": eng.rho if model == "6dof" else [eng.rho(k) for k in ("xy", "z", "yaw")],
-                   "parallelism": "instances sharded x%d" % world},
+                   "parallelism": "instances sharded x%d" % world, "batches_in_flight": depth},
         "timed_steps": timed_steps, "timed_s": elapsed,
-        "p50_batch_ms": float(np.median(lat)),
+        "p50_batch_ms": float(np.median(lat)),          # one batch in flight, host clock around launch + synchronize
+        "one_in_flight_solves_per_s": B * world / (float(np.median(lat)) * 1e-3),
         "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),
         "solved_frac": float(stats[1].item()) / total_inst,
         "max_iter_hit_frac": float(stats[3].item()) / total_inst, "infeasible_frac": float(stats[4].item()) / total_inst,
@@ -372,7 +396,10 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "admm_kernel",
                      "counts": "matrix-core flops executed for the iterations the instances needed",
-                     "avg_kernel_ms": avg_kernel_ms, "launches_timed": timed_steps * launches_per_step,
+                     "avg_kernel_ms": avg_kernel_ms,
+                     "avg_kernel_ms_is": "event time of the timed region / launches" if depth == 1 else
+                                         "wall time of the timed region / launches (launches of the handles in flight overlap)",
+                     "launches_timed": timed_steps * launches_per_step,
                      "per_launch_event_ms": per_launch_event_ms,
                      "sustained_mfma_microbench": FP64_MFMA_SUSTAINED_TFLOPS,
                      "executed_flops_per_launch": executed,

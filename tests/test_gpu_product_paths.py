@@ -343,3 +343,37 @@ mpc_node:
         assert abs(s.velocity.x - ro["X"][0][6 * (i + 1) + 3]) < 1e-9
         assert abs(s.acceleration.y - ro["U"][0][3 * i + 1]) < 1e-9
     assert abs(msg.command.acceleration.x - ro["U"][0][0]) < 1e-9 and msg.max_velocity == 10.0
+
+
+# ---------------------------------------------------------------- batches in flight on several handles
+def test_handles_on_their_own_streams_overlap_without_interfering(tg):
+    """What the benchmark's small-batch workloads do: consecutive batches go to different handles,
+    each with its own buffers and HIP stream, so the next batch runs while one tile of the last is
+    still busy with a slow instance.  Every batch's statuses, iteration counts and solutions equal
+    those of the same batch solved alone."""
+    import torch
+    from trajectory_generation_amd import synth
+    N, B, depth = 20, 1024, 3
+    p = tg.mpc12_params(N=N)
+    alone = tg.BatchedMPC12(p)
+    engs = [tg.BatchedMPC12(p) for _ in range(depth)]
+    bufs = [e.alloc(B) for e in engs]
+    streams = [torch.cuda.Stream() for _ in range(depth)]
+    want = []
+    for k in range(depth):
+        x, ref = synth.mpc12(SEED + 3, N, 0.1, B, first=k * B)
+        _to_dev(bufs[k], x, ref)
+        solo = alone.alloc(B)
+        _to_dev(solo, x, ref)
+        alone.solve(solo)
+        want.append({n: solo[n].clone() for n in ("X", "U", "status", "iters")})
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for k in range(depth):
+            engs[k].solve(bufs[k], stream=streams[k])
+    torch.cuda.synchronize()
+    for k in range(depth):
+        assert torch.equal(bufs[k]["status"], want[k]["status"]) and torch.equal(bufs[k]["iters"], want[k]["iters"])
+        ok = (want[k]["status"].reshape(3, -1) == 1).all(0)
+        assert ok.sum() > 0.99 * B
+        assert torch.equal(bufs[k]["X"][:, ok], want[k]["X"][:, ok]) and torch.equal(bufs[k]["U"][:, ok], want[k]["U"][:, ok])
