@@ -256,9 +256,19 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # closed loop: the status and iteration rows of every timed step are kept (one device-to-device
+    # copy each per step) for the per-step failure figures of the line
+    hist = None
+    if closed:
+        hist = (torch.empty((args.steps,) + tuple(buf["status"].shape), dtype=buf["status"].dtype, device=buf["status"].device),
+                torch.empty((args.steps,) + tuple(buf["iters"].shape), dtype=buf["iters"].dtype, device=buf["iters"].device))
+    recording = [False]
+
     def step(i=0):
         if closed:
             eng.solve(buf, warm=True)
+            if recording[0]:
+                hist[0][i].copy_(buf["status"]); hist[1][i].copy_(buf["iters"])
             eng.plant_step(buf)
             eng.ref_shift(buf)
         elif depth > 1:
@@ -288,7 +298,9 @@ def main():
         step(i)
     # exactly --steps steps per timed region; a region shorter than MIN_TIMED_S is repeated (every
     # rank derives the same count from the reduced time of the first one)
+    recording[0] = True
     el, ev = region(args.steps)
+    recording[0] = False
     regions = 1 if closed else max(1, min(200, int(np.ceil(MIN_TIMED_S / max(el, 1e-9)))))
     elapsed, region_ms = el, ev
     for _ in range(regions - 1):
@@ -411,6 +423,23 @@ def main():
                      "monolithic_flops_per_iteration": mono,
                      "reduction_vs_monolithic": mono * 16.0 * stages / (sum(i[0] for i in info) * 2048.0)},
     }
+    if closed:
+        # rank 0's vehicles over the timed steps: a vehicle counts as failed in a step when any stage
+        # of its solve did not end "solved" (the plant then follows the last plan it received)
+        hs = hist[0].cpu().numpy().reshape(args.steps, -1, buf["ld"])[:, :, :B]
+        hi = hist[1].cpu().numpy().reshape(args.steps, -1, buf["ld"])[:, :, :B]
+        failed = (hs != 1).any(1).mean(1); hit = (hs == -2).any(1).mean(1); infeas = (hs == -3).any(1).mean(1)
+        out["closed_loop"] = {
+            "steps": args.steps, "vehicles_rank0": B,
+            "failed_frac_per_step": {"mean": float(failed.mean()), "max": float(failed.max()), "last": float(failed[-1])},
+            "max_iter_hit_frac_per_step": {"mean": float(hit.mean()), "max": float(hit.max()), "last": float(hit[-1])},
+            "infeasible_frac_per_step": {"mean": float(infeas.mean()), "max": float(infeas.max()), "last": float(infeas[-1])},
+            "iters_mean_per_step": {"first": float(hi[0].mean()), "mean": float(hi.mean()), "last": float(hi[-1].mean())},
+            "iters_max": int(hi.max()),
+            "series_every": max(1, args.steps // 10),
+            "failed_frac_series": [float(v) for v in failed[::max(1, args.steps // 10)]],
+            "failed_solve_means": "plant_step is status-gated: the vehicle keeps following its last good plan "
+                                  "(nothing is published for a failed solve, mpc_ros.cpp:428-432)"}
     if not args.no_cpu_baseline and world == 1:
         rho = out["config"]["rho"]
         base, smp = cpu_baseline(model, N, seed_off, args.eps, rho, eng.rho_rows(), args.check, args.check_fine,

@@ -22,7 +22,7 @@ SEED = 0x4D5043
 
 
 def exact(qp, q, l, u, rho):
-    s = O.fixed_rho_settings(rho, eps_abs=1e-8, eps_rel=1e-8, max_iter=40000, warm_start=0)
+    s = O.fixed_rho_settings(rho, eps_abs=1e-8, eps_rel=1e-8, max_iter=40000, warm_start=0, linsys=1)
     w = O.Osqp(qp["P"], qp["A"], qp["q"], qp["l"], qp["u"], s)
     w.update(q=q, l=l, u=u)
     r = w.solve()
@@ -82,24 +82,37 @@ def golden12(name, p, x12, ref12, rho=(1000.0, 1000.0, 200.0)):
     print(name, "ok")
 
 
-if __name__ == "__main__":
+def main(only):
+    want = lambda name: not only or name in only
+    if want("harness"):
+        harness()
+    # seeded random instances (config/mpc.yaml weights, smoothing off): 32 per family and horizon
+    for N in (5, 10, 20, 50):
+        if want("6dof_N%d" % N):
+            p = O.mpc6_params(N=N)
+            x0, ref = O.synth_mpc6(SEED + 2, N, 0.1, 32)
+            golden6("rand_6dof_N%d.npz" % N, p, x0, ref)
+    for N in (5, 10, 20, 50):
+        if want("12state_N%d" % N):
+            p = O.mpc12_params(N=N)
+            x12, ref12 = O.synth_mpc12(SEED + 3, N, 0.1, 32)
+            golden12("rand_12state_N%d.npz" % N, p, x12, ref12)
+
+
+def harness():
     # harness case of test/test_mpc_6dof.cpp:16-83 (smoothing on with weight 10: ctor defaults)
     p = O.mpc6_params(N=20, dt=0.1, state_weight=7000.0, input_weight=500.0, smooth_input_weight=10.0,
                       enable_control_smoothing=True, min_altitude=-1.0)
     x0 = np.array([[0.1, 0, 0, 0, 0, 0.0]]); ref = np.zeros((1, 21, 6)); ref[0, :, 0] = 0.1; ref[0, :, 2] = 1.0
     golden6("harness_6dof.npz", p, x0, ref.reshape(1, -1))
-    # seeded random instances (config/mpc.yaml weights, smoothing off)
-    for N, B in ((5, 6), (10, 6), (20, 6), (50, 3)):
-        p = O.mpc6_params(N=N)
-        x0, ref = O.synth_mpc6(SEED + 2, N, 0.1, B)
-        golden6("rand_6dof_N%d.npz" % N, p, x0, ref)
     # harness case of test/test_mpc_12state.cpp:14-168
     p = O.mpc12_params(N=10, dt=0.1, state_weight=(1000.0, 1000.0, 1000.0), input_weight=(10.0, 10.0, 1.0),
                        max_vel=(12.0, 5.0, 5.0), max_accel=(5.0, 5.0, 10.0), max_jerk=(10.0, 10.0, 10.0))
     x12 = np.array([[0.03, 0, 0, -0.04, 0, 0, 0.1, 0, 0, 0, 0, 0.0]])
     ref12 = np.zeros((1, 11, 12)); ref12[0, :, 6] = 40.0; ref12[0, :, 0] = 4.0; ref12[0, :, 3] = 0.5
     golden12("harness_12state.npz", p, x12, ref12.reshape(1, -1), rho=(100.0, 100.0, 50.0))
-    for N, B in ((5, 4), (10, 4), (20, 4)):
-        p = O.mpc12_params(N=N)
-        x12, ref12 = O.synth_mpc12(SEED + 3, N, 0.1, B)
-        golden12("rand_12state_N%d.npz" % N, p, x12, ref12)
+
+
+if __name__ == "__main__":
+    # python tests/golden/make_golden.py [harness] [6dof_N50] [12state_N20] ...  (no argument: everything)
+    main(set(sys.argv[1:]))

@@ -82,3 +82,36 @@ def test_bench_fixed_total_is_shared_out():
     d = _last_json(r.stdout.decode())
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["instances_total"] == 262144 and d["config"]["instances_rank0"] == 131072
+
+
+def test_bench_closed_loop_reports_failures_per_step():
+    """The closed-loop workloads carry the per-step failure figures: share of vehicles whose solve
+    failed, hit the iteration budget or was certified infeasible in each of the timed steps."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2",
+                        "--workload", "rollout_12state_B8192_N20", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+    d = _last_json(r.stdout.decode())
+    cl = d["closed_loop"]
+    assert cl["steps"] == 40 and cl["vehicles_rank0"] == 8192 and d["config"]["batches_in_flight"] == 1
+    for k in ("failed_frac_per_step", "max_iter_hit_frac_per_step", "infeasible_frac_per_step"):
+        assert 0.0 <= cl[k]["mean"] <= cl[k]["max"] <= 1.0
+    assert cl["failed_frac_per_step"]["max"] < 0.05
+    assert cl["failed_frac_per_step"]["mean"] >= cl["max_iter_hit_frac_per_step"]["mean"]
+    assert len(cl["failed_frac_series"]) >= 10 and cl["iters_mean_per_step"]["last"] <= cl["iters_mean_per_step"]["first"]
+
+
+def test_bench_small_batches_are_kept_in_flight():
+    """mpc_12state_B4096_N20 by default keeps several batches in flight (one handle, buffer set and
+    stream each); --pipeline 1 is the strictly serial figure, and the latency keys are measured
+    with one batch in flight either way."""
+    out = {}
+    for depth in (0, 1):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2",
+                            "--workload", "mpc_12state_B4096_N20", "--no-cpu-baseline", "--pipeline", str(depth)],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+        out[depth] = _last_json(r.stdout.decode())
+    a, b = out[0], out[1]
+    assert a["config"]["batches_in_flight"] > 1 and b["config"]["batches_in_flight"] == 1
+    assert a["iters_hist_rank0"] == b["iters_hist_rank0"] and a["solved_frac"] == b["solved_frac"]
+    assert a["value"] > 1.2 * b["value"]
+    assert abs(b["one_in_flight_solves_per_s"] / b["value"] - 1.0) < 0.25

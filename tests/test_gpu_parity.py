@@ -261,11 +261,13 @@ def test_kernel_info_reports_operator_form(tg):
     assert [e12.kernel_info(k) for k in ("z", "xy", "yaw")] == [(126, False), (2 * 6 * 24, False), (126, False)]
 
 
-def test_12state_stage_by_stage_with_injected_upstream(tg, oracle, golden_dir):
+@pytest.mark.parametrize("horizon", [5, 10, 20, 50])
+def test_12state_stage_by_stage_with_injected_upstream(tg, oracle, golden_dir, horizon):
     """Each stage solved on the GPU with the certified upstream solution injected (the XY bounds
-    are a discontinuous function of the Z solution, so stages are compared one at a time)."""
+    are a discontinuous function of the Z solution, so stages are compared one at a time); 32
+    certified instances per horizon."""
     import torch
-    g = np.load(os.path.join(golden_dir, "rand_12state_N20.npz"))
+    g = np.load(os.path.join(golden_dir, "rand_12state_N%d.npz" % horizon))
     N, B = int(g["N"]), g["x0"].shape[0]
     eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(eps_abs=1e-8, eps_rel=1e-8, max_iter=40000))
     buf = eng.alloc(B)

@@ -136,17 +136,26 @@ def test_harness_6dof(oracle, golden_dir):
 
 
 def test_12state_pipeline_matches_golden(oracle, golden_dir):
-    for name in ("rand_12state_N5.npz", "rand_12state_N10.npz", "harness_12state.npz"):
+    for name in ("rand_12state_N5.npz", "rand_12state_N10.npz", "rand_12state_N20.npz", "rand_12state_N50.npz",
+                 "harness_12state.npz"):
         g = np.load(os.path.join(golden_dir, name))
         vals = dict(zip([str(k) for k in g["param_names"]], g["params"]))
         p = oracle.mpc12_params(N=int(g["N"]), dt=float(g["dt"]))
         for k, v in vals.items():
             setattr(p, k, float(v))
         harness = name.startswith("harness")
-        s = oracle.fixed_rho_settings(1000.0 if harness else 100.0, eps_abs=1e-9, eps_rel=1e-9,
-                                      max_iter=50000, warm_start=0)
+        tight = dict(eps_abs=1e-9, eps_rel=1e-9, max_iter=50000, warm_start=0)
+        if harness:
+            oracle.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+            s = oracle.fixed_rho_settings(1000.0, **tight)
+        else:
+            # the engine's step sizes for these weights (a single rho for every row class needs more
+            # than 50000 iterations at 1e-9 on some of the 32 instances)
+            oracle.set_rho_class_scale(1.0, 10.0, 3.0, 3.0)
+            s = dict(xy=oracle.fixed_rho_settings(500.0, **tight), z=oracle.fixed_rho_settings(500.0, **tight),
+                     yaw=oracle.fixed_rho_settings(200.0, **tight))
         m = oracle.Mpc12(p, s)
-        for b in range(g["x0"].shape[0]):
+        for b in range(g["x0"].shape[0] if int(g["N"]) < 50 else 6):   # N = 50: a sample keeps the CPU suite short
             r = m.loop(g["x0"][b], g["ref"][b])
             if harness:
                 # The harness drives a_z into saturation (d = a_z / a_zmax = 1), where the XY
@@ -163,6 +172,7 @@ def test_12state_pipeline_matches_golden(oracle, golden_dir):
             assert np.abs(r["yaw_ref"] - g["yaw_ref"][b]).max() < 1e-4
             assert np.abs(r["yaw_sol"] - g["yaw_sol"][b]).max() < 1e-4
             assert np.abs(r["X"] - g["X"][b]).max() < 1e-4 and np.abs(r["U"] - g["U"][b]).max() < 1e-4
+    oracle.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
 
 
 def test_warm_start_and_infeasible(oracle):
