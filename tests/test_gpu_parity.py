@@ -297,7 +297,9 @@ def test_golden_6dof_within_1e4_when_tight(tg, golden_dir):
                   input_weight=float(g["input_weight"]), smooth_input_weight=float(g["smooth_input_weight"]),
                   enable_control_smoothing=bool(g["enable_control_smoothing"]),
                   min_altitude=float(g["min_altitude"]), max_vel=tuple(g["max_vel"]), max_accel=tuple(g["max_accel"]))
-        tight = tg.BatchedMPC6(tg.mpc6_params(**kw), tg.make_opts(eps_abs=1e-8, eps_rel=1e-8, max_iter=40000))
+        # N = 50: the far end of the horizon is loosely determined, 1e-8 leaves 1.3e-4 on one of the 32
+        eps = 1e-8 if kw["N"] < 50 else 1e-9
+        tight = tg.BatchedMPC6(tg.mpc6_params(**kw), tg.make_opts(eps_abs=eps, eps_rel=eps, max_iter=100000))
         r = tight.solve_host(g["x0"], g["ref"])
         assert (r["status"] == 1).all(), f
         d = max(np.abs(r["X"] - g["X"]).max(), np.abs(r["U"] - g["U"]).max())
