@@ -626,47 +626,61 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 };
                 if (nit > 0) { if (PAIR && two_r) run(std::true_type{}); else run(std::false_type{}); }
             }
-            STAMP(3);
-            __syncthreads();
-            STAMP(4);
-            {   // stage 2: this wave's tile, D_I r_I + U_I (s^(0) + ... + s^(3))
-                const int blk = P.grp_first[grp_2];
-                const bool two = PAIR && P.grp_cnt[grp_2] == 2;
-                const double *r0p = v0 + ((size_t)blk * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
-                const double *s0p = lds + SB + ((size_t)blk * P.sb_rows + tile_2 * P.lr_q + (lane >> 4)) * 16 + (lane & 15);
-                auto run = [&](auto two_c) __attribute__((always_inline)) {
+            // The tile's own product D_I r_I does not need C r: it is issued before the barrier,
+            // where it fills the matrix pipe while other waves still wait for their operands, and
+            // its accumulators are kept across the barrier.
+            const int blk2 = P.grp_first[grp_2];
+            const bool two2 = PAIR && P.grp_cnt[grp_2] == 2;
+            const bool has2 = P.wj_cnt[wave] > 0;
+            d4 h0 = (d4){0, 0, 0, 0}, h1 = (d4){0, 0, 0, 0};
+            {
+                const double *r0p = v0 + ((size_t)blk2 * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
+                auto runD = [&](auto two_c) __attribute__((always_inline)) {
                     constexpr bool TWO = decltype(two_c)::value;
-                    // the four partial sums of the tile's coefficients are added on the way in
-                    double bf0[5], bf1[TWO ? 5 : 1], sp0[4], sp1[TWO ? 4 : 1];
+                    double bf0[4], bf1[TWO ? 4 : 1];
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
                         bf0[kk] = r0p[kk * 64];
-                        sp0[kk] = s0p[kk * pstride];
-                        if constexpr (TWO) { bf1[kk] = r0p[(size_t)nb * 16 + kk * 64]; sp1[kk] = s0p[(size_t)P.sb_rows * 16 + kk * pstride]; }
+                        if constexpr (TWO) bf1[kk] = r0p[(size_t)nb * 16 + kk * 64];
                     }
-                    bf0[4] = (sp0[0] + sp0[1]) + (sp0[2] + sp0[3]);
-                    if constexpr (TWO) bf1[4] = (sp1[0] + sp1[1]) + (sp1[2] + sp1[3]);
-                    d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
 #pragma unroll
-                    for (int kk = 0; kk < 5; kk++) {
-                        if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf0[kk], c0, 0, 0, 0);
-                        else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf0[kk], c1, 0, 0, 0);
-                        if constexpr (TWO) c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf1[kk], c1, 0, 0, 0);
-                    }
-                    if constexpr (!TWO) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) c0[r] += c1[r];
-                    }
-                    double *o0 = vx + ((size_t)blk * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
-                    const int row0 = tile_2 * 16 + (lane >> 4);   // rows past the block are MFMA padding
-#pragma unroll
-                    for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[r * 64] = c0[r];
-                    if constexpr (TWO) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[(size_t)nb * 16 + r * 64] = c1[r];
+                    for (int kk = 0; kk < 4; kk++) {
+                        if (TWO || !(kk & 1)) h0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf0[kk], h0, 0, 0, 0);
+                        else h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf0[kk], h1, 0, 0, 0);
+                        if constexpr (TWO) h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[kk], bf1[kk], h1, 0, 0, 0);
                     }
                 };
-                if (P.wj_cnt[wave] > 0) { if (PAIR && two) run(std::true_type{}); else run(std::false_type{}); }
+                if (has2) { if (PAIR && two2) runD(std::true_type{}); else runD(std::false_type{}); }
+            }
+            STAMP(3);
+            __syncthreads();
+            STAMP(4);
+            {   // stage 2: + U_I (s^(0) + ... + s^(3)), the four partial sums added on the way in
+                const double *s0p = lds + SB + ((size_t)blk2 * P.sb_rows + tile_2 * P.lr_q + (lane >> 4)) * 16 + (lane & 15);
+                auto run = [&](auto two_c) __attribute__((always_inline)) {
+                    constexpr bool TWO = decltype(two_c)::value;
+                    double sp0[4], sp1[TWO ? 4 : 1];
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+                        sp0[kk] = s0p[kk * pstride];
+                        if constexpr (TWO) sp1[kk] = s0p[(size_t)P.sb_rows * 16 + kk * pstride];
+                    }
+                    h0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[4], (sp0[0] + sp0[1]) + (sp0[2] + sp0[3]), h0, 0, 0, 0);
+                    if constexpr (TWO) h1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dreg[4], (sp1[0] + sp1[1]) + (sp1[2] + sp1[3]), h1, 0, 0, 0);
+                    if constexpr (!TWO) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) h0[r] += h1[r];
+                    }
+                    double *o0 = vx + ((size_t)blk2 * nb + tile_2 * 16 + (lane >> 4)) * 16 + (lane & 15);
+                    const int row0 = tile_2 * 16 + (lane >> 4);   // rows past the block are MFMA padding
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[r * 64] = h0[r];
+                    if constexpr (TWO) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (row0 + 4 * r < nb) o0[(size_t)nb * 16 + r * 64] = h1[r];
+                    }
+                };
+                if (has2) { if (PAIR && two2) run(std::true_type{}); else run(std::false_type{}); }
             }
         } else if constexpr (LR) {
             // Block-row low-rank form: stage 1, s = C r for every block as two partial sums (the
@@ -1633,9 +1647,6 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
         // low-rank operators with register-resident fragments (6-DOF, short horizons)
         if (P.D == 2 && P.nax == 3 && !P.mixed && sym && sep && needc <= 2 && needi <= 1 && needj <= 1 && fits(16) &&
             P.lr_crb == 1 && P.lr_uk == 1) {
-#if TG_HAS(0)
-            if (P.sm && !P.ql) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true, true, false>(P, a, s);
-#endif
 #if TG_HAS(1)
             return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(plain, a, s);
 #endif
