@@ -14,6 +14,7 @@ schedule -- the configuration the headline target is quoted on; with N ranks eve
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -41,7 +42,8 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "mpc_6dof_B262144_N50"
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD at 2.4 GHz)
 FP64_MFMA_SUSTAINED_TFLOPS = 75.7   # tools/microbench/mfma_valu_overlap.hip on the box: register-only MFMA, two chains per SIMD
-PIPELINE = {"mpc_12state_B4096_N20": 8, "mpc_6dof_B4096_N20": 2}   # default batches in flight (--pipeline 0)
+PIPELINE = {"mpc_12state_B4096_N20": 6, "mpc_6dof_B4096_N20": 4,
+            "rollout_12state_B8192_N20": 4}   # closed loop: sub-fleets, each on its own stream   # default batches in flight (--pipeline 0)
 MIN_TIMED_S = 0.5              # shorter regions are repeated until this much has been timed
 PROFILE_ROUND = "r02"
 
@@ -185,6 +187,7 @@ def main():
     ap.add_argument("--grid-cap", type=int, default=0, help="most workgroups per solve (0: what the GPU holds at once, -1: one per tile of 16 instances)")
     ap.add_argument("--lowrank", type=int, default=0, help="K^-1 as diagonal tiles + low-rank rest: 0 where it pays, 1 wherever possible, -1 dense")
     ap.add_argument("--check-fine", type=int, default=0, help="check interval after the first check (0: OSQP's fixed interval, the default everywhere)")
+    ap.add_argument("--hard-first", type=int, default=0, help="a refilled grid takes the likely slow instances first (0) or the batch in its own order (-1)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
     ap.add_argument("--smoothing", action="store_true", help="input smoothing term on (the test mains' setting; config/mpc.yaml has it off)")
@@ -197,6 +200,14 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
+
+    # Batches in flight (below) live on HIP streams of their own.  HIP spreads a process's streams
+    # over GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise) and streams that share a
+    # queue run in turn: with four to six handles in flight that leaves some of them behind a slow
+    # launch.  Eight queues give every handle its own; read by the runtime when it starts.
+    depth = args.pipeline if args.pipeline > 0 else PIPELINE.get(args.workload, 1)
+    if depth > 1:
+        os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
     import torch
     import torch.distributed as dist
@@ -221,15 +232,18 @@ def main():
     else:
         first, B = rank * count, count                     # fixed per GPU: every rank owns its own slab
     opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check,
-                        check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank)
+                        check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank, hard_first=args.hard_first)
     closed = args.workload.startswith("rollout")
     # A batch that is one wave of workgroups (B = 4096: 256 tiles on 256 CUs) ends with the chip
     # waiting for its slowest tile; a server keeps the next batches in flight meanwhile.  Steps go
     # round-robin to `depth` handles, each with its own buffers and stream.  The per-batch latency
     # is measured separately with one batch in flight.
-    depth = args.pipeline if args.pipeline > 0 else (1 if closed else PIPELINE.get(args.workload, 1))
-    if closed and depth > 1:
-        sys.exit("--pipeline > 1 is for the open-loop workloads (a closed-loop step depends on the one before)")
+    # A closed-loop step depends on the one before, but vehicles do not depend on each other: there
+    # the `depth` handles own one sub-fleet of B / depth vehicles each, and every step advances all of
+    # them, each on its own stream, so a sub-fleet waiting for a slow solve does not hold up the rest.
+    if closed and B % depth:
+        sys.exit("--pipeline must divide the fleet for the closed-loop workloads")
+    Bh = B // depth if closed else B                       # instances per handle
 
     def make_engine():
         if model == "6dof":
@@ -239,18 +253,20 @@ def main():
     gen = synth.mpc6 if model == "6dof" else synth.mpc12
     engs = [make_engine() for _ in range(depth)]
     eng = engs[0]
-    bufs = [e.alloc(B) for e in engs]
+    bufs = [e.alloc(Bh) for e in engs]
     buf = bufs[0]
     streams = [torch.cuda.Stream(device=local) for _ in range(depth)] if depth > 1 else [None]
-    for a in range(0, B, 32768):                           # generated and uploaded in slabs
-        b = min(a + 32768, B)
-        x0, ref = gen(SEED + seed_off, N, 0.1, b - a, first + a)
-        if args.stress:
-            x0, ref = synth.stress(model, x0, ref, N)
-        buf["x0"][:, a:b] = torch.from_numpy(np.ascontiguousarray(x0.T)).cuda()
-        buf["ref"][:, a:b] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()
-    for other in bufs[1:]:
-        other["x0"].copy_(buf["x0"]); other["ref"].copy_(buf["ref"])
+    for h, hb in enumerate(bufs if closed else bufs[:1]):
+        for a in range(0, Bh, 32768):                      # generated and uploaded in slabs
+            b = min(a + 32768, Bh)
+            x0, ref = gen(SEED + seed_off, N, 0.1, b - a, first + h * Bh + a)
+            if args.stress:
+                x0, ref = synth.stress(model, x0, ref, N)
+            hb["x0"][:, a:b] = torch.from_numpy(np.ascontiguousarray(x0.T)).cuda()
+            hb["ref"][:, a:b] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()
+    if not closed:
+        for other in bufs[1:]:
+            other["x0"].copy_(buf["x0"]); other["ref"].copy_(buf["ref"])
 
     def barrier():
         if world > 1:
@@ -260,17 +276,21 @@ def main():
     # copy each per step) for the per-step failure figures of the line
     hist = None
     if closed:
-        hist = (torch.empty((args.steps,) + tuple(buf["status"].shape), dtype=buf["status"].dtype, device=buf["status"].device),
-                torch.empty((args.steps,) + tuple(buf["iters"].shape), dtype=buf["iters"].dtype, device=buf["iters"].device))
+        hist = [(torch.empty((args.steps,) + tuple(hb["status"].shape), dtype=hb["status"].dtype, device=hb["status"].device),
+                 torch.empty((args.steps,) + tuple(hb["iters"].shape), dtype=hb["iters"].dtype, device=hb["iters"].device))
+                for hb in bufs]
     recording = [False]
 
     def step(i=0):
         if closed:
-            eng.solve(buf, warm=True)
-            if recording[0]:
-                hist[0][i].copy_(buf["status"]); hist[1][i].copy_(buf["iters"])
-            eng.plant_step(buf)
-            eng.ref_shift(buf)
+            for h in range(depth):
+                st = streams[h]
+                engs[h].solve(bufs[h], warm=True, stream=st)
+                if recording[0]:
+                    with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                        hist[h][0][i].copy_(bufs[h]["status"]); hist[h][1][i].copy_(bufs[h]["iters"])
+                engs[h].plant_step(bufs[h], stream=st)
+                engs[h].ref_shift(bufs[h], stream=st)
         elif depth > 1:
             engs[i % depth].solve(bufs[i % depth], stream=streams[i % depth])
         else:
@@ -319,8 +339,9 @@ def main():
     kern_ms, kern_launches = tg.timing_read(reset=True)
     tg.timing_enable(False)
 
-    iters = buf["iters"].cpu().numpy().reshape(-1, buf["ld"])[:, :B]
-    status = buf["status"].cpu().numpy().reshape(-1, buf["ld"])[:, :B]
+    view = lambda hb, name: hb[name].cpu().numpy().reshape(-1, hb["ld"])[:, :Bh]
+    iters = np.concatenate([view(hb, "iters") for hb in (bufs if closed else bufs[:1])], axis=1)
+    status = np.concatenate([view(hb, "status") for hb in (bufs if closed else bufs[:1])], axis=1)
     stats = torch.tensor([float(iters.sum()), float((status == 1).all(0).sum()), float(B),
                           float((status == -2).any(0).sum()), float((status == -3).any(0).sum())],
                          dtype=torch.float64, device=red_dev)
@@ -353,7 +374,7 @@ def main():
     total_inst = float(stats[2].item())
     value = total_inst * timed_steps / elapsed
     stages = iters.shape[0]
-    launches_per_step = stages
+    launches_per_step = stages * (depth if closed else 1)
     if model == "6dof":
         info = [eng.kernel_info()]
         dense = float(iters.sum()) * dense_flops_per_iteration(model, N)
@@ -393,10 +414,11 @@ def main():
         "config": {"workload": args.workload, "instances_total": int(total_inst), "instances_rank0": B, "horizon_N": N,
                    "horizon_limit": "N <= 50 (iterates of 16 instances stay in the 160 KiB of LDS)",
                    "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check,
-                   "check_fine": args.check_fine, "grid_cap": args.grid_cap, "lowrank": args.lowrank,
+                   "check_fine": args.check_fine, "grid_cap": args.grid_cap, "lowrank": args.lowrank, "hard_first": args.hard_first,
                    "smoothing": bool(args.smoothing), "inputs": "stress" if args.stress else "seeded",
                    "rho": eng.rho if model == "6dof" else [eng.rho(k) for k in ("xy", "z", "yaw")],
-                   "parallelism": "instances sharded x%d" % world, "batches_in_flight": depth},
+                   "parallelism": "instances sharded x%d" % world, "batches_in_flight": depth,
+                   "instances_per_handle": Bh},
         "timed_steps": timed_steps, "timed_s": elapsed,
         "p50_batch_ms": float(np.median(lat)),          # one batch in flight, host clock around launch + synchronize
         "one_in_flight_solves_per_s": B * world / (float(np.median(lat)) * 1e-3),
@@ -426,8 +448,8 @@ def main():
     if closed:
         # rank 0's vehicles over the timed steps: a vehicle counts as failed in a step when any stage
         # of its solve did not end "solved" (the plant then follows the last plan it received)
-        hs = hist[0].cpu().numpy().reshape(args.steps, -1, buf["ld"])[:, :, :B]
-        hi = hist[1].cpu().numpy().reshape(args.steps, -1, buf["ld"])[:, :, :B]
+        hs = np.concatenate([hh[0].cpu().numpy().reshape(args.steps, -1, hb["ld"])[:, :, :Bh] for hh, hb in zip(hist, bufs)], axis=2)
+        hi = np.concatenate([hh[1].cpu().numpy().reshape(args.steps, -1, hb["ld"])[:, :, :Bh] for hh, hb in zip(hist, bufs)], axis=2)
         failed = (hs != 1).any(1).mean(1); hit = (hs == -2).any(1).mean(1); infeas = (hs == -3).any(1).mean(1)
         out["closed_loop"] = {
             "steps": args.steps, "vehicles_rank0": B,

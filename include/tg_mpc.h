@@ -104,6 +104,12 @@ typedef struct {
      * operators), 1: wherever the computed inverse has the structure to working precision,
      * -1: dense always.  The two forms agree to rounding (1e-15 relative). */
     int    lowrank;
+    /* Order in which a grid whose slots are refilled (grid_cap above) takes the instances of the
+     * batch.  0: the sixteenth of the batch whose reference strays farthest from where the initial
+     * state coasts to is taken first -- those instances tend to need the most iterations, and
+     * started last they would leave the GPU waiting for them; -1: batch order.  An instance's
+     * result does not depend on it. */
+    int    hard_first;
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

@@ -92,7 +92,9 @@ def test_bench_closed_loop_reports_failures_per_step():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
     d = _last_json(r.stdout.decode())
     cl = d["closed_loop"]
-    assert cl["steps"] == 40 and cl["vehicles_rank0"] == 8192 and d["config"]["batches_in_flight"] == 1
+    # the fleet runs as four sub-fleets of 2048 vehicles, each on its own handle and stream
+    assert cl["steps"] == 40 and cl["vehicles_rank0"] == 8192 and d["config"]["batches_in_flight"] == 4
+    assert d["config"]["instances_per_handle"] == 2048 and sum(d["iters_hist_rank0"].values()) == 3 * 8192
     for k in ("failed_frac_per_step", "max_iter_hit_frac_per_step", "infeasible_frac_per_step"):
         assert 0.0 <= cl[k]["mean"] <= cl[k]["max"] <= 1.0
     assert cl["failed_frac_per_step"]["max"] < 0.05

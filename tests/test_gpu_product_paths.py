@@ -377,3 +377,39 @@ def test_handles_on_their_own_streams_overlap_without_interfering(tg):
         ok = (want[k]["status"].reshape(3, -1) == 1).all(0)
         assert ok.sum() > 0.99 * B
         assert torch.equal(bufs[k]["X"][:, ok], want[k]["X"][:, ok]) and torch.equal(bufs[k]["U"][:, ok], want[k]["U"][:, ok])
+
+
+# ---------------------------------------------------------------- order in which a refilled grid takes the batch
+def test_hard_first_order_changes_nothing_but_the_order(tg):
+    """A refilled grid takes the sixteenth of the batch that is likely to need the most iterations
+    first (tg_solver_opts.hard_first, default).  Statuses, iteration counts and solutions equal
+    those in batch order bit for bit, with an infeasible instance in the batch; and the
+    instances that needed the most iterations are indeed among those the ordering puts first."""
+    import torch
+    from trajectory_generation_amd import synth
+    N, B = 50, 8192
+    x0, ref = synth.mpc6(SEED + 4, N, 0.1, B)
+    x0[4321, 4] = -40.0                               # |v_y(0)| > v_max: infeasible
+    res = []
+    for hf in (-1, 0):
+        eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(hard_first=hf))
+        assert eng.get_opts().hard_first == hf
+        buf = eng.alloc(B)
+        _to_dev(buf, x0, ref)
+        eng.solve(buf)
+        res.append({k: buf[k].clone() for k in ("X", "U", "status", "iters")})
+    a, b = res
+    assert torch.equal(a["status"], b["status"]) and torch.equal(a["iters"], b["iters"])
+    ok = a["status"][:B] == 1
+    assert int(ok.sum()) == B - 1 and int(a["status"][4321]) == -3
+    assert torch.equal(a["X"][:, :B][:, ok], b["X"][:, :B][:, ok]) and torch.equal(a["U"][:, :B][:, ok], b["U"][:, :B][:, ok])
+    # the score the ordering uses: farthest the reference strays from where the initial state coasts to
+    t = np.arange(N + 1) * 0.1
+    R = ref.reshape(B, N + 1, 6)[:, :, :3]
+    coast = x0[:, None, :3] + x0[:, None, 3:] * t[None, :, None]
+    score = np.abs(R - coast).max(axis=(1, 2))
+    it = a["iters"][:B].cpu().numpy()
+    slow = (it >= 100) & (np.arange(B) != 4321)
+    assert slow.sum() >= 1
+    cut = np.sort(score)[-B // 8]
+    assert (score[slow] >= cut).mean() >= 0.75      # a predictor, not an oracle

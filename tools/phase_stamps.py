@@ -14,17 +14,25 @@ CHK = int(sys.argv[4]) if len(sys.argv) > 4 else iters
 REAL = len(sys.argv) > 5 and sys.argv[5] == "real"     # eps 1e-3 on a batch of 32768: exits and slot refills included
 B = 32768 if REAL else 4096
 opts = tg.make_opts() if REAL else tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=CHK, eps_prim_inf=0.0)
-eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts)
-x0, ref = synth.mpc6(1, N, 0.1, B)
+if model == "6dof":
+    eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts)
+    x0, ref = synth.mpc6(1, N, 0.1, B)
+else:                      # 12z / 12xy / 12yaw: one stage of the 12-state chain (upstream solution: zeros)
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N), opts)
+    x0, ref = synth.mpc12(1, N, 0.1, B)
 buf = eng.alloc(B)
 buf["x0"][:, :B] = torch.from_numpy(np.ascontiguousarray(x0.T)).cuda()
 buf["ref"][:, :B] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()
-eng.solve(buf); torch.cuda.synchronize()
+if model == "6dof":
+    eng.solve(buf)
+else:
+    eng.solve_stage(model[2:], buf)
+torch.cuda.synchronize()
 acc = buf["U"][0, :16].cpu().numpy().reshape(2, 8)
 ck = buf["X"][0, :16].cpu().numpy().reshape(2, 8)
 acc = acc / (ck[0][7] * 25 if REAL else iters)
 names = ["rhs", "bar", "mfma1", "bar", "mfma2", "bar", "proj", "bar+"]
-print("cycles per iteration (kernel info %s)" % (eng.kernel_info(),))
+print("cycles per iteration (kernel info %s)" % (eng.kernel_info() if model == "6dof" else eng.kernel_info(model[2:]),))
 print("wave " + " ".join("%8s" % n for n in names) + "    total")
 for w in range(2):
     print("%4d " % (4 * w) + " ".join("%8.0f" % v for v in acc[w]) + " %8.0f" % acc[w].sum())

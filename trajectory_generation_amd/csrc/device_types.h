@@ -97,6 +97,16 @@ struct BatchArgs {
     int queue_base;
     int *queue_mem;          // one int of device memory owned by the stage (may be null)
     int grid_cap;            // 0: as many workgroups as fit on the device at once; > 0: at most this many
+    // Order in which a refilled grid takes the instances: list[ticket] (null: batch order).
+    // launch_admm builds it in order_list when the batch goes through the queue (order_list,
+    // order_score [B] and order_hdr [kOrderHdrBytes] are the stage's own device memory; may be null).
+    const int *list;
+    int *order_list;
+    double *order_score;
+    unsigned long long *order_hdr;
 };
+
+constexpr int kOrderBins = 256;
+constexpr size_t kOrderHdrBytes = 8 + kOrderBins * 4 + 2 * 4 + 8;
 
 } // namespace tg

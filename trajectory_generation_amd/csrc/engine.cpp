@@ -86,6 +86,8 @@ struct DevStage {
     int lowrank_mode = 0;     // 0: when it pays, 1: whenever the operators allow it, -1: never
     int *d_queue = nullptr;   // ticket counter of the kernel's instance queue
     int grid_cap = 0;
+    int hard_first = 0;       // 0: a refilled grid takes the likely slow instances first, -1: batch order
+    int *d_olist = nullptr; double *d_oscore = nullptr; unsigned long long *d_ohdr = nullptr; int order_cap = 0;
     double *d_qw = nullptr, *d_lt = nullptr, *d_ut = nullptr;
     int32_t *d_qrr = nullptr, *d_x0r = nullptr, *d_ovb = nullptr, *d_ovm = nullptr;
     // warm-start iterates of the instance slots
@@ -100,6 +102,8 @@ struct DevStage {
         if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
         HIP_TRY(hipMalloc((void **)&d_queue, sizeof(int)));
         grid_cap = o.grid_cap;
+        hard_first = o.hard_first;
+        hard_first = o.hard_first;
         lowrank_mode = o.lowrank;
         if ((rc = upload(sp.q_w, &d_qw))) return rc;
         if ((rc = upload(sp.l_t, &d_lt))) return rc;
@@ -318,6 +322,7 @@ struct DevStage {
         hipFree(d_Mfrag); hipFree(d_DUfrag); hipFree(d_Wfrag); hipFree(d_queue);
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
         hipFree(d_ovm); hipFree(d_warm); hipFree(d_res);
+        hipFree(d_olist); hipFree(d_oscore); hipFree(d_ohdr);
     }
     void kernel_info(int *mfma, int *lowrank) const
     {
@@ -345,6 +350,18 @@ struct DevStage {
         HIP_TRY(hipMalloc((void **)&d_warm, rows * cap * sizeof(double)));
         warm_cap = cap;
         HIP_TRY(hipMemsetAsync(d_warm, 0, rows * cap * sizeof(double), s));
+        return TG_OK;
+    }
+    // work arrays of the instance ordering (launch_admm uses them when the batch goes through the queue)
+    int ensure_order(int B)
+    {
+        if (B <= order_cap) return TG_OK;
+        hipFree(d_olist); hipFree(d_oscore); d_olist = nullptr; d_oscore = nullptr; order_cap = 0;
+        const int cap = (B + 255) / 256 * 256;
+        HIP_TRY(hipMalloc((void **)&d_olist, (size_t)cap * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_oscore, (size_t)cap * sizeof(double)));
+        if (!d_ohdr) HIP_TRY(hipMalloc((void **)&d_ohdr, kOrderHdrBytes));
+        order_cap = cap;
         return TG_OK;
     }
     // primal / dual residual of every instance at its exit, [2][res_cap]
@@ -377,6 +394,12 @@ struct DevStage {
             if (rc) return rc;
             a.res = d_res; a.res_ld = res_cap;
             a.queue_mem = grid_cap >= 0 ? d_queue : nullptr;
+        }
+        a.list = nullptr; a.order_list = nullptr; a.order_score = nullptr; a.order_hdr = nullptr;
+        if (!no_alloc && grid_cap >= 0 && hard_first >= 0 && a.B > 16 * 256) {   // smaller batches never go through the queue
+            int rc = ensure_order(a.B);
+            if (rc) return rc;
+            a.order_list = d_olist; a.order_score = d_oscore; a.order_hdr = d_ohdr;
         }
         a.grid_cap = grid_cap;
         const char *why = "";
@@ -430,7 +453,7 @@ struct DevStage {
         out->rho = sp.rho; out->sigma = dev.sigma; out->alpha = dev.alpha;
         out->eps_abs = dev.eps_abs; out->eps_rel = dev.eps_rel; out->eps_prim_inf = dev.eps_prim_inf;
         out->max_iter = dev.max_iter; out->check_termination = dev.check; out->check_fine = dev.check_fine;
-        out->grid_cap = grid_cap; out->lowrank = dev.lr;
+        out->grid_cap = grid_cap; out->hard_first = hard_first; out->lowrank = dev.lr;
         for (int k = 0; k < 4; k++) out->rho_scale[k] = sp.rho_scale[k];
     }
     // options that do not enter the factorised operator can change on a live handle
@@ -439,6 +462,7 @@ struct DevStage {
         dev.alpha = o.alpha; dev.eps_abs = o.eps_abs; dev.eps_rel = o.eps_rel; dev.eps_prim_inf = o.eps_prim_inf;
         dev.max_iter = o.max_iter; dev.check = o.check_termination; dev.check_fine = o.check_fine;
         grid_cap = o.grid_cap;
+        hard_first = o.hard_first;
     }
     int get(int which, double *out) const
     {
@@ -508,7 +532,7 @@ extern "C" {
 void tg_default_opts(tg_solver_opts *o)
 {
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
-    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0; o->grid_cap = 0; o->lowrank = 0;
+    o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0; o->grid_cap = 0; o->lowrank = 0; o->hard_first = 0;
     for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }
@@ -734,6 +758,7 @@ int tg_mpc6_set_opts(tg_mpc6 *h, const tg_solver_opts *o)
     h->o.alpha = o->alpha; h->o.eps_abs = o->eps_abs; h->o.eps_rel = o->eps_rel; h->o.eps_prim_inf = o->eps_prim_inf;
     h->o.max_iter = o->max_iter; h->o.check_termination = o->check_termination; h->o.check_fine = o->check_fine;
     h->o.grid_cap = o->grid_cap;
+    h->o.hard_first = o->hard_first;
     return TG_OK;
 }
 int tg_mpc6_last_residuals(tg_mpc6 *h, int B, double *prim, double *dual)
@@ -1120,6 +1145,7 @@ int tg_mpc12_set_opts(tg_mpc12 *h, const tg_solver_opts *o)
     h->o.alpha = o->alpha; h->o.eps_abs = o->eps_abs; h->o.eps_rel = o->eps_rel; h->o.eps_prim_inf = o->eps_prim_inf;
     h->o.max_iter = o->max_iter; h->o.check_termination = o->check_termination; h->o.check_fine = o->check_fine;
     h->o.grid_cap = o->grid_cap;
+    h->o.hard_first = o->hard_first;
     return TG_OK;
 }
 int tg_mpc12_last_residuals(tg_mpc12 *h, int stage, int B, double *prim, double *dual)

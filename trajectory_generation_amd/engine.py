@@ -16,14 +16,15 @@ def _torch():
 
 
 def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000,
-              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0, grid_cap=0, lowrank=0):
+              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0, grid_cap=0, lowrank=0, hard_first=0):
     """rho <= 0 and rho_scale entries of 0 select the engine's built-in choices; rho_scale is
     (position, velocity, acceleration, input) multipliers of rho on the box rows;
     eps_prim_inf = 0 switches the primal infeasibility test off; check_fine > 0: after the first
     check (iteration check_termination) test every check_fine iterations, 0: OSQP's fixed interval;
     grid_cap: most workgroups a solve launches (0: what the GPU holds at once, < 0: one per tile of
     16 instances); a smaller grid refills its instance slots from the rest of the batch;
-    lowrank: K^-1 as diagonal tiles + low-rank rest (0: where it pays, 1: wherever possible, -1: dense)."""
+    lowrank: K^-1 as diagonal tiles + low-rank rest (0: where it pays, 1: wherever possible, -1: dense).
+    hard_first: a refilled grid takes the likely slow instances first (0; -1: batch order)."""
     o = capi.SolverOpts()
     capi.load().tg_default_opts(C.byref(o))
     o.rho_scale[:] = [float(v) for v in rho_scale]
@@ -33,6 +34,7 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
     o.check_fine = check_fine
     o.grid_cap = grid_cap
     o.lowrank = lowrank
+    o.hard_first = hard_first
     return o
 
 
