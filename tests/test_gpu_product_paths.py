@@ -413,3 +413,25 @@ def test_hard_first_order_changes_nothing_but_the_order(tg):
     assert slow.sum() >= 1
     cut = np.sort(score)[-B // 8]
     assert (score[slow] >= cut).mean() >= 0.75      # a predictor, not an oracle
+
+
+def test_hard_first_order_12state_chain(tg):
+    """The same for the three-stage chain (the ordering reads each stage's own reference rows and
+    skips gated instances): 8192 vehicles, two slots' worth per workgroup, results bit for bit
+    those of batch order."""
+    import torch
+    from trajectory_generation_amd import synth
+    N, B = 20, 8192
+    x, ref = synth.mpc12(SEED + 3, N, 0.1, B)
+    res = []
+    for hf in (-1, 0):
+        eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(hard_first=hf))
+        buf = eng.alloc(B)
+        _to_dev(buf, x, ref)
+        eng.solve(buf)
+        res.append({k: buf[k].clone() for k in ("X", "U", "status", "iters")})
+    a, b = res
+    assert torch.equal(a["status"], b["status"]) and torch.equal(a["iters"], b["iters"])
+    ok = (a["status"].reshape(3, -1)[:, :B] == 1).all(0)
+    assert 0.99 * B < int(ok.sum()) < B               # the batch holds gated instances too
+    assert torch.equal(a["X"][:, :B][:, ok], b["X"][:, :B][:, ok]) and torch.equal(a["U"][:, :B][:, ok], b["U"][:, :B][:, ok])
