@@ -258,7 +258,7 @@ def test_kernel_info_reports_operator_form(tg):
     assert n50.kernel_info() == (3 * (3 * 40 + 10 * 5), True)
     assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(lowrank=-1)).kernel_info() == (3 * 10 * 40, False)
     e12 = tg.BatchedMPC12(tg.mpc12_params(N=20))
-    assert [e12.kernel_info(k) for k in ("z", "xy", "yaw")] == [(126, False), (2 * 6 * 24, False), (126, False)]
+    assert [e12.kernel_info(k) for k in ("z", "xy", "yaw")] == [(126, False), (2 * 6 * 21, False), (126, False)]
 
 
 @pytest.mark.parametrize("horizon", [5, 10, 20, 50])

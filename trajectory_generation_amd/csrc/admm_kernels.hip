@@ -108,7 +108,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 // UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
 //        operator's own are zero).
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // the D_I / U_I fragments of its tiles -- so one ring of PD loads in flight serves the whole
     // MFMA phase.  The items' LDS offsets are wave-uniform and looked up once, here.
     constexpr bool STREAM = KSREG == 0;
-    constexpr int PD = kRingDepth;
+    constexpr int PD = PDT;
     constexpr int KD = 4 + UK;                      // fragments of a second-stage item
     const int laneoff = (lane >> 4) * 16 + (lane & 15);
     // wave-uniform base of the stream; a load is base + lane, so that the base stays in scalar registers
@@ -1670,10 +1670,11 @@ size_t admm_lds_bytes(const StageDev &P)
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT>;
+    if (KSREG == 0 && P.ring != PDT) return hipErrorInvalidValue;
     if ((P.sm != 0) != SM || (P.ql != 0) != QL) return hipErrorInvalidValue;   // the LDS layout follows P.ql
     if (KSREG == 0 && (!P.Wfrag || (LR && (P.lr_np > 2 || P.lr_ukp != UK)))) return hipErrorInvalidValue;
     const size_t lds_bytes = admm_lds_bytes(P);
@@ -1819,7 +1820,12 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
 #endif
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
 #if TG_HAS(10)
-        if (sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(plain, a, s);
+        // the ring depth that pads the k range least (host choice; N = 20: 21 k-steps = 3 rounds of 7)
+        if (sep && needc <= 2 && needi <= 2) {
+            if (P.ring == 7) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true, false, false, false, 2, false, 7>(plain, a, s);
+            if (P.ring == 6) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true, false, false, false, 2, false, 6>(plain, a, s);
+            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(plain, a, s);
+        }
 #endif
 #if TG_HAS(11)
         if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(plain, a, s);

@@ -25,6 +25,7 @@ struct StageDev {
     int N, D, nax, mixed;        // horizon, chain order, axes, XY mixed rows present
     int n_int, nb, nrb, ks;      // rows of all blocks, rows of one block (= block stride), 16-row blocks, k steps
     int ks_alloc;                // k steps stored per (operator, row block): ks + kRingDepth zero steps
+    int ring;                    // k steps a wave keeps in flight from L2 (streamed variants): kRingDepth, or less where that pads ks less
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];
     int separate_xt;
@@ -44,7 +45,7 @@ struct StageDev {
     const double *DUfrag;
     int lr_ukp;                  // k-steps of U per tile as stored in the wave streams (>= lr_uk, zero padded)
     // Streamed variants: wave w reads the fragments of its items in the order of use from
-    // Wfrag + wave_off[w] * 64: every first-stage item (wi_*) as wi_nr ring rounds of kRingDepth
+    // Wfrag + wave_off[w] * 64: every first-stage item (wi_*) as wi_nr ring rounds of `ring`
     // k-steps starting at k-step wi_k0 (zero fragments past ks), then (low-rank form) 4 + lr_ukp
     // fragments per tile (wj_*), then zero fragments for the ring to run out into.  In the low-rank
     // form the k range of a row block of C is cut in two items whose results are partial sums

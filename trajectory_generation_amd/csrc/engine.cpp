@@ -146,6 +146,16 @@ struct DevStage {
                 (sp.n_int - sp.nb) + 64 <= rows_init) { dev.lr = 1; dev.lr_np = 4; }
         }
         const bool streamed_lr = dev.lr && dev.lr_np == 2;
+        // ring depth of the fragment streams: an item is a whole number of ring rounds, so the
+        // depth that pads the k range least wins where a variant is compiled for it (dense XY)
+        dev.ring = kRingDepth;
+        if (xy && !dev.lr && mdl.N + 1 <= dev.nwaves * 64 / kTileDev && 2 * dev.nrb <= 2 * kAdmmWaves) {   // the two-cell, two-item variant
+            int best = (dev.ks + kRingDepth - 1) / kRingDepth * kRingDepth;
+            for (int r = kRingDepth - 1; r >= 6; r--) {
+                const int padded = (dev.ks + r - 1) / r * r;
+                if (padded < best) { best = padded; dev.ring = r; }
+            }
+        }
         if (streamed_lr) {   // the second partial sum needs LDS of its own: dropped where the horizon leaves none
             dev.separate_xt = 0; dev.sm = 0; dev.ql = 0;
             if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.lr_np = 1;
@@ -222,7 +232,7 @@ struct DevStage {
             for (int w = 0; w < kAdmmWaves; w++) out[w] = best_bins[w];
             return true;
         };
-        const int PD = kRingDepth, rounds = (dev.ks + PD - 1) / PD;
+        const int PD = dev.ring, rounds = (dev.ks + PD - 1) / PD;
         {
             // dense: (group, row block); low-rank: (group, row block of the stacked C[, part of the k
             // range]), then (group, tile)
