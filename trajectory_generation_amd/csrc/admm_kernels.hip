@@ -108,7 +108,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 // UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
 //        operator's own are zero).
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -152,7 +152,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // the single MFMA item of a wave whose fragments are register resident, looked up once
     const int grp_r = P.wi_grp[wave][0], rb_r = P.wi_rb[wave][0];
     const bool two_r = PAIR && P.grp_cnt[grp_r] == 2;
-    const int boff_r = (P.grp_first[grp_r] * nb + (lane >> 4)) * 16 + (lane & 15);
+    // KPART == 2 (register-resident dense fragments, fewer row blocks than waves): some row blocks
+    // are split in two items, each half of the k range, so that every wave has work; the second
+    // half's product goes to a vector of its own (VX2) and the projection adds the two.
+    static_assert(KPART == 1 || (KSREG > 0 && !LR && SEP && MAXIT == 1), "k-range parts: register-resident dense variants only");
+    const int k0_r = KPART == 2 ? P.wi_k0[wave][0] : 0;          // first k-step of the wave's item
+    const int kl_r = KPART == 2 ? P.wi_nr[wave][0] : KSREG;      // its k-steps
+    const int part_r = KPART == 2 ? P.wi_part[wave][0] : 0;
+    const int boff_r = (P.grp_first[grp_r] * nb + 4 * k0_r + (lane >> 4)) * 16 + (lane & 15);
     // LR with register-resident fragments (short horizons): C r is formed as four partial sums,
     // one quarter of the k range per first-stage item, so that eight items fill the eight waves;
     // the second stage adds the partials and applies U_I: xt_I = D_I r_I + U_I sum_p s_I^(p).  A wave
@@ -174,14 +181,15 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         const int grp = grp_r, rb = rb_r;
 #pragma unroll
         for (int kk = 0; kk < KSREG; kk++) {
-            const bool in = nit > 0 && kk < ks;
-            mreg[kk] = in ? P.Mfrag[(((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc + kk) * 64 + lane] : 0.0;
+            const bool in = nit > 0 && kk < kl_r && k0_r + kk < ks;
+            mreg[kk] = in ? P.Mfrag[(((size_t)P.grp_op[grp] * nrb + rb) * P.ks_alloc + k0_r + kk) * 64 + lane] : 0.0;
         }
     }
 
     const int V0 = 0;
     const int VX = SEP ? (n_int + S) * 16 : 0;
-    const int WEQ = (SEP ? 2 : 1) * (n_int + S) * 16;
+    const int X2 = KPART == 2 ? (n_int + S) * 16 : 0;                        // VX2 = VX + X2: products of the second k-range parts
+    const int WEQ = (SEP ? 2 + (KPART == 2 ? 1 : 0) : 1) * (n_int + S) * 16;
     const int WMX = WEQ + (ncell * D + D) * 16;
     const int SB = WMX + (MIXED ? (N1 * 6 + 6) * 16 : 0);                   // LR: C r of every block, [blocks][sb_rows][16]
     const int QV = SB + (LR ? P.lr_np * (n_int / nb) * P.sb_rows * 16 : 0);   // QL: q of every cell, [ncell + 1][16]
@@ -227,6 +235,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     bool mact[MAXM];
     int i_var[MAXC];     // index of the cell's first variable, relative to V0 / VX
     int i_prev[MAXC];    // absolute index of the previous cell's variables in VX (or ZERO)
+    int i_prev2[KPART == 2 ? MAXC : 1];   // the same in VX2
     int i_wnext[MAXC];   // absolute index of the next cell's dynamics-row w (or ZERO)
     int i_ct[MAXC];      // absolute index of the cell's axis in the constant table
     int i_bg[MAXC];      // absolute index of the cell's dynamics-row bound (BGT at step 0, else ZERO)
@@ -244,6 +253,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         for (int k = 0; k < NAX; k++) if (ax == k) abase = P.axis_base[k];
         i_var[cc] = act ? (abase + st * S) * 16 + t : n_int * 16 + t;
         i_prev[cc] = (act && st > 0) ? VX + i_var[cc] - S * 16 : ZERO + t;
+        if constexpr (KPART == 2) i_prev2[cc] = (act && st > 0) ? i_prev[cc] + X2 : ZERO + t;
         i_wnext[cc] = (act && st < N) ? WEQ + ((c + 1) * D) * 16 + t : ZERO + t;
         i_ct[cc] = CTAB + ax * S * 3;
         i_bg[cc] = (act && st == 0) ? BGT + ax * D * 16 + t : ZERO + t;
@@ -825,11 +835,12 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (nit > 0) {
                     const double *bp0 = v0 + boff_r;
                     const double *bp1 = bp0 + (size_t)nb * 16;
-                    auto run = [&](auto two_c) __attribute__((always_inline)) {
+                    auto run = [&](auto two_c, auto cnt_c) __attribute__((always_inline)) {
                         constexpr bool TWO = decltype(two_c)::value;
-                        double bf0[KSREG], bf1[TWO ? KSREG : 1];
+                        constexpr int CNT = decltype(cnt_c)::value;      // k-steps of the item (KSREG, or half of it)
+                        double bf0[CNT], bf1[TWO ? CNT : 1];
 #pragma unroll
-                        for (int kk = 0; kk < KSREG; kk++) {
+                        for (int kk = 0; kk < CNT; kk++) {
                             bf0[kk] = bp0[kk * 64];
                             if constexpr (TWO) bf1[kk] = bp1[kk * 64];
                         }
@@ -839,7 +850,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         // in case the wave has its SIMD to itself during this phase.
                         d4 c0 = (d4){0, 0, 0, 0}, c1 = (d4){0, 0, 0, 0};
 #pragma unroll
-                        for (int kk = 0; kk < KSREG; kk++) {
+                        for (int kk = 0; kk < CNT; kk++) {
 #if !(TG_ABLATE & 1)
                             if (TWO || !(kk & 1)) c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c0, 0, 0, 0);
                             else c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[kk], bf0[kk], c1, 0, 0, 0);
@@ -853,10 +864,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                             for (int r = 0; r < 4; r++) c0[r] += c1[r];
                         }
-                        if constexpr (SEP) store(VX + P.grp_first[grp_r] * nb * 16 + rb_r * 256, nb - rb_r * 16, TWO, c0, c1);
+                        if constexpr (SEP) store(VX + part_r * X2 + P.grp_first[grp_r] * nb * 16 + rb_r * 256, nb - rb_r * 16, TWO, c0, c1);
                         else { acc0[0] = c0; if constexpr (PAIR) acc1[0] = c1; }
                     };
-                    if (PAIR && two_r) run(std::true_type{}); else run(std::false_type{});
+                    constexpr int KH = (KSREG + 1) / 2;
+                    if (KPART == 2 && kl_r <= KH) run(std::false_type{}, std::integral_constant<int, KH>{});
+                    else if (PAIR && two_r) run(std::true_type{}, std::integral_constant<int, KSREG>{});
+                    else run(std::false_type{}, std::integral_constant<int, KSREG>{});
                 }
             } else {
                 // the wave's items follow one another in its fragment stream (each a whole number
@@ -927,6 +941,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         xt[j][k] = xin[k * 16]; xp[j][k] = xpr[k * 16];
+                        if constexpr (KPART == 2) {   // + the second k-range part (zero where a row block is not split)
+                            xt[j][k] += xin[X2 + k * 16];
+                            xp[j][k] += lds[i_prev2[cc] + k * 16];
+                        }
                         if constexpr (G > 1) {
                             if (MIXED && (k == 1 || k == 2)) { bnd[j][k][1] = hiv[cc][k - 1]; bnd[j][k][0] = -bnd[j][k][1]; }
                             else if (REGC) { bnd[j][k][1] = c_hi[cc][k]; bnd[j][k][0] = k == 0 ? c_lo0[cc] : -c_hi[cc][k]; }
@@ -1663,18 +1681,19 @@ static hipError_t launch_order(const StageDev &P, const BatchArgs &a, hipStream_
 size_t admm_lds_bytes(const StageDev &P)
 {
     const int S = P.D + 1, ncell = P.nax * (P.N + 1);
-    size_t rows = (size_t)(P.separate_xt ? 2 : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
+    size_t rows = (size_t)(P.separate_xt ? 2 + (P.kpart == 2 ? 1 : 0) : 1) * (P.n_int + S) + (size_t)ncell * P.D + P.D +
                   (P.mixed ? (size_t)(P.N + 1) * 6 + 6 : 0) + 8 + (size_t)P.nax * P.D +
                   (P.lr ? (size_t)P.lr_np * (P.n_int / P.nb) * P.sb_rows : 0) + (P.ql ? (size_t)ncell + 1 : 0);
     return rows * 16 * sizeof(double) + ((size_t)P.nax * S * 3 + 2) * sizeof(double) + (9 + kAdmmWaves + 1) * 16 * sizeof(double);
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT, KPART>;
     if (KSREG == 0 && P.ring != PDT) return hipErrorInvalidValue;
+    if ((P.kpart == 2) != (KPART == 2)) return hipErrorInvalidValue;
     if ((P.sm != 0) != SM || (P.ql != 0) != QL) return hipErrorInvalidValue;   // the LDS layout follows P.ql
     if (KSREG == 0 && (!P.Wfrag || (LR && (P.lr_np > 2 || P.lr_ukp != UK)))) return hipErrorInvalidValue;
     const size_t lds_bytes = admm_lds_bytes(P);
@@ -1747,7 +1766,7 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     // register-resident variants read 4 * KSREG B rows from the start of every block: they must stay
     // inside the zero-initialised part of LDS
     const int S = P.D + 1;
-    const int rows_init = (P.separate_xt ? 2 : 1) * (P.n_int + S) + ncell * P.D + P.D +
+    const int rows_init = (P.separate_xt ? 2 + (P.kpart == 2 ? 1 : 0) : 1) * (P.n_int + S) + ncell * P.D + P.D +
                           (P.mixed ? (P.N + 1) * 6 + 6 : 0) + 8 + P.nax * P.D;
     // the variants with few cells per thread keep the box bounds in registers as (hi, -hi) for
     // every slot but the first
@@ -1835,7 +1854,10 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
 #endif
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
 #if TG_HAS(13)
-        if (sym && sep && needc <= 1 && needi <= 1 && fits(21)) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(plain, a, s);
+        if (sym && sep && needc <= 1 && needi <= 1 && fits(21)) {
+            if (P.kpart == 2) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true, false, false, false, 2, false, kRingDepth, 2>(plain, a, s);
+            return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(plain, a, s);
+        }
 #endif
 #if TG_HAS(14)
         if (sym && sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(plain, a, s);

@@ -25,6 +25,7 @@ struct StageDev {
     int N, D, nax, mixed;        // horizon, chain order, axes, XY mixed rows present
     int n_int, nb, nrb, ks;      // rows of all blocks, rows of one block (= block stride), 16-row blocks, k steps
     int ks_alloc;                // k steps stored per (operator, row block): ks + kRingDepth zero steps
+    int kpart;                   // 2: register-resident dense variant with some row blocks split in two k-range items (wi_k0, wi_nr = k-steps, wi_part)
     int ring;                    // k steps a wave keeps in flight from L2 (streamed variants): kRingDepth, or less where that pads ks less
     int ngrp, grp_first[4], grp_cnt[4], grp_op[4]; // block groups sharing an operator
     int axis_base[kMaxAxes];

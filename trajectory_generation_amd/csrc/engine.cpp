@@ -183,6 +183,21 @@ struct DevStage {
                 if (dev.lr_ukp != 1 || admm_lds_bytes(dev) > (size_t)160 * 1024) { dev.ql = 0; dev.sm = 0; dev.lr_ukp = 2; dev.sb_rows = sb_rows; }
             }
         }
+        // Single-axis stages with register-resident dense fragments have fewer row blocks than waves
+        // (N = 20: six): as many row blocks as there are idle waves are split in two items of half the
+        // k range each, so that every SIMD carries the same number of MFMAs; the halves' products
+        // land in two vectors the projection adds.  (The conditions are those of launch_admm's
+        // register-resident single-axis variant.)
+        dev.kpart = 0;
+        if (!six && !xy && !dev.lr && regs_dense && dev.separate_xt && dev.nrb < kAdmmWaves) {
+            bool sym = true;
+            for (int a = 0; a < sp.nax; a++)
+                for (int k = 1; k <= sp.D; k++) sym = sym && sp.lb[a][k] == -sp.ub[a][k];
+            dev.kpart = 2;
+            const int S = sp.D + 1, ncell = sp.nax * (mdl.N + 1);
+            const int rows_init = 3 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
+            if (!sym || (sp.n_int - sp.nb) + 4 * 21 > rows_init || admm_lds_bytes(dev) > (size_t)160 * 1024) dev.kpart = 0;
+        }
         if (dev.lr && admm_lds_bytes(dev) > (size_t)160 * 1024) return fail(TG_E_ARG, "horizon too long: iterates do not fit the 160 KiB LDS");
         // deal the MFMA items: longest first onto the least loaded SIMD (waves w, w + 4, ... of a
         // workgroup share a SIMD), then onto its least loaded wave
@@ -246,6 +261,14 @@ struct DevStage {
                     for (int rb = 0; rb < dev.lr_crb; rb++) {
                         items.push_back({gi, rb, cnt * ra * PD, 0, ra, 0});
                         if (rb2 > 0) items.push_back({gi, rb, cnt * rb2 * PD, ra * PD, rb2, 1});
+                    }
+                } else if (dev.kpart == 2) {
+                    // the last row blocks in halves of the k range (nr: k-steps of the item)
+                    const int nsplit = std::min(dev.nrb, kAdmmWaves - dev.nrb), kh = (dev.ks + 1) / 2;
+                    for (int rb = 0; rb < dev.nrb; rb++) {
+                        if (rb < dev.nrb - nsplit) { items.push_back({gi, rb, cnt * dev.ks, 0, dev.ks, 0}); continue; }
+                        items.push_back({gi, rb, cnt * kh, 0, kh, 0});
+                        items.push_back({gi, rb, cnt * (dev.ks - kh), kh, dev.ks - kh, 1});
                     }
                 } else {
                     for (int rb = 0; rb < dev.nrb; rb++) items.push_back({gi, rb, cnt * rounds * PD, 0, rounds, 0});
