@@ -345,7 +345,17 @@ def main():
     stats = torch.tensor([float(iters.sum()), float((status == 1).all(0).sum()), float(B),
                           float((status == -2).any(0).sum()), float((status == -3).any(0).sum())],
                          dtype=torch.float64, device=red_dev)
-    imax = torch.tensor([float(iters.max())], dtype=torch.float64, device=red_dev)
+    # OSQP's residuals at the check that ended each solve (handle 0's last batch), maxima over the
+    # solved instances
+    solved = (status == 1)
+    if model == "6dof":
+        res = [engs[0].last_residuals(Bh)]
+    else:
+        res = [engs[0].last_residuals(k, Bh) for k in ("z", "xy", "yaw")]
+    okh = solved[:, :Bh]
+    rmax = [max((float(r[0][okh[k]].max()) if okh[k].any() else 0.0) for k, r in enumerate(res)),
+            max((float(r[1][okh[k]].max()) if okh[k].any() else 0.0) for k, r in enumerate(res))]
+    imax = torch.tensor([float(iters.max())] + rmax, dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(imax, op=dist.ReduceOp.MAX)
@@ -422,7 +432,9 @@ def main():
         "timed_steps": timed_steps, "timed_s": elapsed,
         "p50_batch_ms": float(np.median(lat)),          # one batch in flight, host clock around launch + synchronize
         "one_in_flight_solves_per_s": B * world / (float(np.median(lat)) * 1e-3),
-        "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax.item()),
+        "iters_mean": float(stats[0].item()) / total_inst / stages, "iters_max": float(imax[0].item()),
+        "max_pri_res": float(imax[1].item()), "max_dua_res": float(imax[2].item()),
+        "qp_solves_per_s": value * stages,
         "solved_frac": float(stats[1].item()) / total_inst,
         "max_iter_hit_frac": float(stats[3].item()) / total_inst, "infeasible_frac": float(stats[4].item()) / total_inst,
         "iters_hist_rank0": {str(int(k)): int(v) for k, v in zip(*np.unique(iters, return_counts=True))},

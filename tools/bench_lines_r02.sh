@@ -24,3 +24,8 @@ run n20_12state_smooth --workload mpc_12state_B4096_N20 --steps 200 --pipeline 1
 run rollout_12state --workload rollout_12state_B8192_N20 --steps 500 --no-cpu-baseline
 run rollout_6dof --workload rollout_6dof_B8192_N20 --steps 500 --no-cpu-baseline
 run rollout_6dof_budget250 --workload rollout_6dof_B8192_N20 --steps 500 --max-iter 250 --no-cpu-baseline
+run n20_6dof_smooth --workload mpc_6dof_B4096_N20 --steps 200 --pipeline 1 --smoothing --no-cpu-baseline
+run n20_6dof_eps1e5 --workload mpc_6dof_B4096_N20 --steps 100 --pipeline 1 --eps 1e-5 --no-cpu-baseline
+run n50_eps1e5 --workload mpc_6dof_B32768_N50 --steps 5 --eps 1e-5 --no-cpu-baseline
+run n20_12state_stress --workload mpc_12state_B4096_N20 --steps 100 --pipeline 1 --stress --no-cpu-baseline
+run n20_12state_eps1e5 --workload mpc_12state_B4096_N20 --steps 10 --pipeline 1 --eps 1e-5 --no-cpu-baseline
