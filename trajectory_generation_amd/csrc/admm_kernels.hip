@@ -1689,13 +1689,13 @@ size_t admm_lds_bytes(const StageDev &P)
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
           bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1>
-static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s)
+static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why)
 {
     auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT, KPART>;
-    if (KSREG == 0 && P.ring != PDT) return hipErrorInvalidValue;
-    if ((P.kpart == 2) != (KPART == 2)) return hipErrorInvalidValue;
-    if ((P.sm != 0) != SM || (P.ql != 0) != QL) return hipErrorInvalidValue;   // the LDS layout follows P.ql
-    if (KSREG == 0 && (!P.Wfrag || (LR && (P.lr_np > 2 || P.lr_ukp != UK)))) return hipErrorInvalidValue;
+    if (KSREG == 0 && P.ring != PDT) { *why = "internal: ring depth of the stage and of the kernel variant differ"; return hipErrorInvalidValue; }
+    if ((P.kpart == 2) != (KPART == 2)) { *why = "internal: k-range parts of the stage and of the kernel variant differ"; return hipErrorInvalidValue; }
+    if ((P.sm != 0) != SM || (P.ql != 0) != QL) { *why = "internal: box-row form of the stage and of the kernel variant differ"; return hipErrorInvalidValue; }   // the LDS layout follows P.ql
+    if (KSREG == 0 && (!P.Wfrag || (LR && (P.lr_np > 2 || P.lr_ukp != UK)))) { *why = "internal: fragment streams of the stage do not match the kernel variant"; return hipErrorInvalidValue; }
     const size_t lds_bytes = admm_lds_bytes(P);
     // the dynamic LDS limit of a kernel is per device and sticky: raise it when it has to grow
     // (per-variant caches, shared by every handle and host thread of the process)
@@ -1762,7 +1762,7 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     const int needc = P.mixed ? 2 * ((P.N + 1 + stride - 1) / stride) : (ncell + stride - 1) / stride;
     int needi = 0;
     for (int w = 0; w < P.nwaves; w++) needi = P.wi_cnt[w] > needi ? P.wi_cnt[w] : needi;
-    if (admm_lds_bytes(P) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
+    if (admm_lds_bytes(P) > kLdsLimit) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
     // register-resident variants read 4 * KSREG B rows from the start of every block: they must stay
     // inside the zero-initialised part of LDS
     const int S = P.D + 1;
@@ -1785,14 +1785,14 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     // Development builds compile a subset of the variants (-DTG_VARIANTS=mask, bit = TG_HAS index).
     StageDev plain = P;          // variants without the s form / q in LDS
     plain.sm = 0; plain.ql = 0;
-    if (admm_lds_bytes(plain) > 160 * 1024) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
+    if (admm_lds_bytes(plain) > kLdsLimit) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
     single.sm = 0; single.ql = 0;
     if (P.lr && P.lr_np == 4) {
         // low-rank operators with register-resident fragments (6-DOF, short horizons)
         if (P.D == 2 && P.nax == 3 && !P.mixed && sym && sep && needc <= 2 && needi <= 1 && needj <= 1 && fits(16) &&
             P.lr_crb == 1 && P.lr_uk == 1) {
 #if TG_HAS(1)
-            return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(plain, a, s);
+            return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(plain, a, s, why);
 #endif
         }
         *why = "internal: no register-resident low-rank variant for this stage";
@@ -1806,64 +1806,64 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
 #if TG_HAS(2)
             // (step-major cells, SMJ with MAXC = 6, were measured at N = 50: 20350 against 20000 cycles
             // per iteration -- the per-axis constants then travel through spilled scalar registers)
-            if (P.sm && P.ql && P.lr_ukp == 1) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s);
+            if (P.sm && P.ql && P.lr_ukp == 1) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s, why);
 #endif
 #if TG_HAS(3)
-            return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(plain, a, s);
+            return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(plain, a, s, why);
 #endif
         }
 #if TG_HAS(4)
         if (P.D == 3 && P.nax == 2 && P.mixed && needc <= 2 && items <= 2)
-            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, false, true>(plain, a, s);
+            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, false, true>(plain, a, s, why);
 #endif
 #if TG_HAS(5)
         if (P.D == 3 && P.nax == 2 && P.mixed && needc <= 4 && items <= 4)
-            return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false, true>(plain, a, s);
+            return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false, true>(plain, a, s, why);
 #endif
 #if TG_HAS(6)
         if (P.D == 3 && P.nax == 1 && !P.mixed && needc <= 2 && items <= 2)
-            return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, false, true>(plain, a, s);
+            return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, false, true>(plain, a, s, why);
 #endif
         *why = "horizon too long for the compiled kernel variants";
         return hipErrorInvalidValue;
     }
     if (P.D == 2 && P.nax == 3 && !P.mixed) {
 #if TG_HAS(7)
-        if (sym && sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(plain, a, s);
+        if (sym && sep && needc <= 2 && needi <= 1 && fits(16)) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true>(plain, a, s, why);
 #endif
 #if TG_HAS(8)
-        if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(plain, a, s);
+        if (sep && needc <= 5 && needi <= 3) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, true>(plain, a, s, why);
 #endif
 #if TG_HAS(9)
-        if (needc <= 8 && needi <= 4) return launch_admm_t<512, 2, 3, false, 8, 4, true, 0, false>(single, a, s);
+        if (needc <= 8 && needi <= 4) return launch_admm_t<512, 2, 3, false, 8, 4, true, 0, false>(single, a, s, why);
 #endif
     } else if (P.D == 3 && P.nax == 2 && P.mixed) {
 #if TG_HAS(10)
         // the ring depth that pads the k range least (host choice; N = 20: 21 k-steps = 3 rounds of 7)
         if (sep && needc <= 2 && needi <= 2) {
-            if (P.ring == 7) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true, false, false, false, 2, false, 7>(plain, a, s);
-            if (P.ring == 6) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true, false, false, false, 2, false, 6>(plain, a, s);
-            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(plain, a, s);
+            if (P.ring == 7) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true, false, false, false, 2, false, 7>(plain, a, s, why);
+            if (P.ring == 6) return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true, false, false, false, 2, false, 6>(plain, a, s, why);
+            return launch_admm_t<512, 3, 2, true, 2, 2, false, 0, true>(plain, a, s, why);
         }
 #endif
 #if TG_HAS(11)
-        if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(plain, a, s);
+        if (sep && needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, true>(plain, a, s, why);
 #endif
 #if TG_HAS(12)
-        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false>(single, a, s);
+        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 2, true, 4, 4, false, 0, false>(single, a, s, why);
 #endif
     } else if (P.D == 3 && P.nax == 1 && !P.mixed) {
 #if TG_HAS(13)
         if (sym && sep && needc <= 1 && needi <= 1 && fits(21)) {
-            if (P.kpart == 2) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true, false, false, false, 2, false, kRingDepth, 2>(plain, a, s);
-            return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(plain, a, s);
+            if (P.kpart == 2) return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true, false, false, false, 2, false, kRingDepth, 2>(plain, a, s, why);
+            return launch_admm_t<512, 3, 1, false, 1, 1, false, 21, true>(plain, a, s, why);
         }
 #endif
 #if TG_HAS(14)
-        if (sym && sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(plain, a, s);
+        if (sym && sep && needc <= 2 && needi <= 2) return launch_admm_t<512, 3, 1, false, 2, 2, false, 0, true>(plain, a, s, why);
 #endif
 #if TG_HAS(15)
-        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 1, false, 4, 4, false, 0, false>(single, a, s);
+        if (needc <= 4 && needi <= 4) return launch_admm_t<512, 3, 1, false, 4, 4, false, 0, false>(single, a, s, why);
 #endif
     }
     *why = "horizon too long for the compiled kernel variants";

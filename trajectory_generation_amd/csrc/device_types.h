@@ -108,6 +108,8 @@ struct BatchArgs {
     unsigned long long *order_hdr;
 };
 
+// dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static share (the block-wide vote helpers keep a few words there)
+constexpr size_t kLdsLimit = (size_t)160 * 1024 - 512;
 constexpr int kOrderBins = 256;
 constexpr size_t kOrderHdrBytes = 8 + kOrderBins * 4 + 2 * 4 + 8;
 

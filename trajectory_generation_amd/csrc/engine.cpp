@@ -158,14 +158,14 @@ struct DevStage {
         }
         if (streamed_lr) {   // the second partial sum needs LDS of its own: dropped where the horizon leaves none
             dev.separate_xt = 0; dev.sm = 0; dev.ql = 0;
-            if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.lr_np = 1;
+            if (admm_lds_bytes(dev) > kLdsLimit) dev.lr_np = 1;
         }
         // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
         // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
         // the iterates of the 16 instances still fit the 160 KiB of LDS
         dev.separate_xt = streamed_lr ? 0 : 1;   // the streamed low-rank form writes xt over the rhs, tile by tile
         dev.sm = 0; dev.ql = 0; dev.lr_ukp = 2;
-        if (admm_lds_bytes(dev) > (size_t)160 * 1024) dev.separate_xt = 0;
+        if (admm_lds_bytes(dev) > kLdsLimit) dev.separate_xt = 0;
         // 6-DOF: the boxes are the same for every instance and every call of the handle; when each
         // contains zero the kernel keeps a box row's (z, y) as the one number they are projected from.
         // Long horizons also move q of the position slots to LDS (five cells per thread: registers).
@@ -180,7 +180,7 @@ struct DevStage {
                 const int sb_rows = dev.sb_rows;
                 dev.ql = 1;
                 if (dev.lr_uk == 1 && dev.lr_q == 4) { dev.lr_ukp = 1; dev.sb_rows = dev.lr_crb * 16; }   // no read past a tile's own four coefficients
-                if (dev.lr_ukp != 1 || admm_lds_bytes(dev) > (size_t)160 * 1024) { dev.ql = 0; dev.sm = 0; dev.lr_ukp = 2; dev.sb_rows = sb_rows; }
+                if (dev.lr_ukp != 1 || admm_lds_bytes(dev) > kLdsLimit) { dev.ql = 0; dev.sm = 0; dev.lr_ukp = 2; dev.sb_rows = sb_rows; }
             }
         }
         // Single-axis stages with register-resident dense fragments have fewer row blocks than waves
@@ -196,9 +196,9 @@ struct DevStage {
             dev.kpart = 2;
             const int S = sp.D + 1, ncell = sp.nax * (mdl.N + 1);
             const int rows_init = 3 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
-            if (!sym || (sp.n_int - sp.nb) + 4 * 21 > rows_init || admm_lds_bytes(dev) > (size_t)160 * 1024) dev.kpart = 0;
+            if (!sym || (sp.n_int - sp.nb) + 4 * 21 > rows_init || admm_lds_bytes(dev) > kLdsLimit) dev.kpart = 0;
         }
-        if (dev.lr && admm_lds_bytes(dev) > (size_t)160 * 1024) return fail(TG_E_ARG, "horizon too long: iterates do not fit the 160 KiB LDS");
+        if (dev.lr && admm_lds_bytes(dev) > kLdsLimit) return fail(TG_E_ARG, "horizon too long: iterates do not fit the 160 KiB LDS");
         // deal the MFMA items: longest first onto the least loaded SIMD (waves w, w + 4, ... of a
         // workgroup share a SIMD), then onto its least loaded wave
         struct Item { int grp, rb, cost, k0, nr, part; };
