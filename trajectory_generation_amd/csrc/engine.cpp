@@ -123,80 +123,86 @@ struct DevStage {
             dev.grp_first[dev.ngrp] = b; dev.grp_cnt[dev.ngrp] = cnt; dev.grp_op[dev.ngrp] = sp.op_of_block[b];
             dev.ngrp++; b += cnt;
         }
-        // Long horizons apply the operators in block-row low-rank form (fewer MFMAs and fragment
-        // bytes per iteration); short ones keep the dense fragments in registers.
-        {
-            const int stride = dev.nwaves * 64 / kTileDev, ncell = sp.nax * (mdl.N + 1);
-            const int cells = (ncell + stride - 1) / stride;
-            const bool in_registers = (six && cells <= 2 && dev.ks <= 16) || (!six && !xy && cells <= 1 && dev.ks <= 21);
-            regs_dense = in_registers;
-            const int dense_mfma = dev.nrb * dev.ks, lr_mfma = sp.lr_crb * dev.ks + dev.nrb * (4 + sp.lr_uk);
-            dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
-            dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
-            // streamed low-rank form: C r as two partial sums (the k range of a row block of C is
-            // cut in two items, so that the first stage spreads evenly over the waves)
-            dev.lr_np = 2;
-            // short 6-DOF horizons: the low-rank form with register-resident fragments and C r as
-            // four partial sums (one first-stage item per wave)
-            // (its B-operand reads run up to 64 rows past the start of the last block: they must
-            // stay inside the zero-initialised LDS, as launch_admm checks)
-            const int S = sp.D + 1;
-            const int rows_init = 2 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
-            if (lowrank_mode >= 0 && six && in_registers && sp.lr_q == 4 && sp.lr_crb == 1 && sp.lr_uk == 1 &&
-                (sp.n_int - sp.nb) + 64 <= rows_init) { dev.lr = 1; dev.lr_np = 4; }
-        }
-        const bool streamed_lr = dev.lr && dev.lr_np == 2;
-        // ring depth of the fragment streams: an item is a whole number of ring rounds, so the
-        // depth that pads the k range least wins where a variant is compiled for it (dense XY)
-        dev.ring = kRingDepth;
-        if (xy && !dev.lr && mdl.N + 1 <= dev.nwaves * 64 / kTileDev && 2 * dev.nrb <= 2 * kAdmmWaves) {   // the two-cell, two-item variant
-            int best = (dev.ks + kRingDepth - 1) / kRingDepth * kRingDepth;
-            for (int r = kRingDepth - 1; r >= 6; r--) {
-                const int padded = (dev.ks + r - 1) / r * r;
-                if (padded < best) { best = padded; dev.ring = r; }
+        // (second attempt: the low-rank form was chosen or asked for but its C r vectors do not fit
+        // the LDS beside the iterates -- the dense form is taken instead)
+        for (int attempt = 0; attempt < 2; attempt++) {
+            const int lowrank_mode = attempt == 0 ? this->lowrank_mode : -1;
+            // Long horizons apply the operators in block-row low-rank form (fewer MFMAs and fragment
+            // bytes per iteration); short ones keep the dense fragments in registers.
+            {
+                const int stride = dev.nwaves * 64 / kTileDev, ncell = sp.nax * (mdl.N + 1);
+                const int cells = (ncell + stride - 1) / stride;
+                const bool in_registers = (six && cells <= 2 && dev.ks <= 16) || (!six && !xy && cells <= 1 && dev.ks <= 21);
+                regs_dense = in_registers;
+                const int dense_mfma = dev.nrb * dev.ks, lr_mfma = sp.lr_crb * dev.ks + dev.nrb * (4 + sp.lr_uk);
+                dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
+                dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
+                // streamed low-rank form: C r as two partial sums (the k range of a row block of C is
+                // cut in two items, so that the first stage spreads evenly over the waves)
+                dev.lr_np = 2;
+                // short 6-DOF horizons: the low-rank form with register-resident fragments and C r as
+                // four partial sums (one first-stage item per wave)
+                // (its B-operand reads run up to 64 rows past the start of the last block: they must
+                // stay inside the zero-initialised LDS, as launch_admm checks)
+                const int S = sp.D + 1;
+                const int rows_init = 2 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
+                if (lowrank_mode >= 0 && six && in_registers && sp.lr_q == 4 && sp.lr_crb == 1 && sp.lr_uk == 1 &&
+                    (sp.n_int - sp.nb) + 64 <= rows_init) { dev.lr = 1; dev.lr_np = 4; }
             }
-        }
-        if (streamed_lr) {   // the second partial sum needs LDS of its own: dropped where the horizon leaves none
-            dev.separate_xt = 0; dev.sm = 0; dev.ql = 0;
-            if (admm_lds_bytes(dev) > kLdsLimit) dev.lr_np = 1;
-        }
-        // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
-        // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
-        // the iterates of the 16 instances still fit the 160 KiB of LDS
-        dev.separate_xt = streamed_lr ? 0 : 1;   // the streamed low-rank form writes xt over the rhs, tile by tile
-        dev.sm = 0; dev.ql = 0; dev.lr_ukp = 2;
-        if (admm_lds_bytes(dev) > kLdsLimit) dev.separate_xt = 0;
-        // 6-DOF: the boxes are the same for every instance and every call of the handle; when each
-        // contains zero the kernel keeps a box row's (z, y) as the one number they are projected from.
-        // Long horizons also move q of the position slots to LDS (five cells per thread: registers).
-        if (six) {
-            bool zero_inside = true;
-            for (int a = 0; a < sp.nax; a++)
-                for (int k = 0; k <= sp.D; k++) zero_inside = zero_inside && sp.lb[a][k] <= 0.0 && sp.ub[a][k] >= 0.0;
-            dev.sm = (zero_inside && streamed_lr) ? 1 : 0;   // (measured slower with register-resident fragments: 5650 against 5240 cycles per iteration at N = 20)
-            if (dev.sm && streamed_lr) {
-                // the long-horizon variant is compiled with the s form, q in LDS and one k-step of
-                // U_I per tile (no input smoothing), or with none of them
-                const int sb_rows = dev.sb_rows;
-                dev.ql = 1;
-                if (dev.lr_uk == 1 && dev.lr_q == 4) { dev.lr_ukp = 1; dev.sb_rows = dev.lr_crb * 16; }   // no read past a tile's own four coefficients
-                if (dev.lr_ukp != 1 || admm_lds_bytes(dev) > kLdsLimit) { dev.ql = 0; dev.sm = 0; dev.lr_ukp = 2; dev.sb_rows = sb_rows; }
+            const bool streamed_lr = dev.lr && dev.lr_np == 2;
+            // ring depth of the fragment streams: an item is a whole number of ring rounds, so the
+            // depth that pads the k range least wins where a variant is compiled for it (dense XY)
+            dev.ring = kRingDepth;
+            if (xy && !dev.lr && mdl.N + 1 <= dev.nwaves * 64 / kTileDev && 2 * dev.nrb <= 2 * kAdmmWaves) {   // the two-cell, two-item variant
+                int best = (dev.ks + kRingDepth - 1) / kRingDepth * kRingDepth;
+                for (int r = kRingDepth - 1; r >= 6; r--) {
+                    const int padded = (dev.ks + r - 1) / r * r;
+                    if (padded < best) { best = padded; dev.ring = r; }
+                }
             }
-        }
-        // Single-axis stages with register-resident dense fragments have fewer row blocks than waves
-        // (N = 20: six): as many row blocks as there are idle waves are split in two items of half the
-        // k range each, so that every SIMD carries the same number of MFMAs; the halves' products
-        // land in two vectors the projection adds.  (The conditions are those of launch_admm's
-        // register-resident single-axis variant.)
-        dev.kpart = 0;
-        if (!six && !xy && !dev.lr && regs_dense && dev.separate_xt && dev.nrb < kAdmmWaves) {
-            bool sym = true;
-            for (int a = 0; a < sp.nax; a++)
-                for (int k = 1; k <= sp.D; k++) sym = sym && sp.lb[a][k] == -sp.ub[a][k];
-            dev.kpart = 2;
-            const int S = sp.D + 1, ncell = sp.nax * (mdl.N + 1);
-            const int rows_init = 3 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
-            if (!sym || (sp.n_int - sp.nb) + 4 * 21 > rows_init || admm_lds_bytes(dev) > kLdsLimit) dev.kpart = 0;
+            if (streamed_lr) {   // the second partial sum needs LDS of its own: dropped where the horizon leaves none
+                dev.separate_xt = 0; dev.sm = 0; dev.ql = 0;
+                if (admm_lds_bytes(dev) > kLdsLimit) dev.lr_np = 1;
+            }
+            // a second on-chip vector for xt: the MFMA results are stored as soon as an item is done
+            // (no accumulators held across a barrier, one barrier less per iteration); taken whenever
+            // the iterates of the 16 instances still fit the 160 KiB of LDS
+            dev.separate_xt = streamed_lr ? 0 : 1;   // the streamed low-rank form writes xt over the rhs, tile by tile
+            dev.sm = 0; dev.ql = 0; dev.lr_ukp = 2;
+            if (admm_lds_bytes(dev) > kLdsLimit) dev.separate_xt = 0;
+            // 6-DOF: the boxes are the same for every instance and every call of the handle; when each
+            // contains zero the kernel keeps a box row's (z, y) as the one number they are projected from.
+            // Long horizons also move q of the position slots to LDS (five cells per thread: registers).
+            if (six) {
+                bool zero_inside = true;
+                for (int a = 0; a < sp.nax; a++)
+                    for (int k = 0; k <= sp.D; k++) zero_inside = zero_inside && sp.lb[a][k] <= 0.0 && sp.ub[a][k] >= 0.0;
+                dev.sm = (zero_inside && streamed_lr) ? 1 : 0;   // (measured slower with register-resident fragments: 5650 against 5240 cycles per iteration at N = 20)
+                if (dev.sm && streamed_lr) {
+                    // the long-horizon variant is compiled with the s form, q in LDS and one k-step of
+                    // U_I per tile (no input smoothing), or with none of them
+                    const int sb_rows = dev.sb_rows;
+                    dev.ql = 1;
+                    if (dev.lr_uk == 1 && dev.lr_q == 4) { dev.lr_ukp = 1; dev.sb_rows = dev.lr_crb * 16; }   // no read past a tile's own four coefficients
+                    if (dev.lr_ukp != 1 || admm_lds_bytes(dev) > kLdsLimit) { dev.ql = 0; dev.sm = 0; dev.lr_ukp = 2; dev.sb_rows = sb_rows; }
+                }
+            }
+            // Single-axis stages with register-resident dense fragments have fewer row blocks than waves
+            // (N = 20: six): as many row blocks as there are idle waves are split in two items of half the
+            // k range each, so that every SIMD carries the same number of MFMAs; the halves' products
+            // land in two vectors the projection adds.  (The conditions are those of launch_admm's
+            // register-resident single-axis variant.)
+            dev.kpart = 0;
+            if (!six && !xy && !dev.lr && regs_dense && dev.separate_xt && dev.nrb < kAdmmWaves) {
+                bool sym = true;
+                for (int a = 0; a < sp.nax; a++)
+                    for (int k = 1; k <= sp.D; k++) sym = sym && sp.lb[a][k] == -sp.ub[a][k];
+                dev.kpart = 2;
+                const int S = sp.D + 1, ncell = sp.nax * (mdl.N + 1);
+                const int rows_init = 3 * (sp.n_int + S) + ncell * sp.D + sp.D + 8 + sp.nax * sp.D;
+                if (!sym || (sp.n_int - sp.nb) + 4 * 21 > rows_init || admm_lds_bytes(dev) > kLdsLimit) dev.kpart = 0;
+            }
+            if (!(dev.lr && admm_lds_bytes(dev) > kLdsLimit)) break;
         }
         if (dev.lr && admm_lds_bytes(dev) > kLdsLimit) return fail(TG_E_ARG, "horizon too long: iterates do not fit the 160 KiB LDS");
         // deal the MFMA items: longest first onto the least loaded SIMD (waves w, w + 4, ... of a
