@@ -108,7 +108,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 // UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
 //        operator's own are zero).
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, bool UNI = false>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -276,9 +276,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 
     // per-axis constants of cell slot cc: scalar kernel arguments when the slot's axis is known at
     // compile time, else the LDS table
-    auto crho = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.rho_box[cc % NAX][k] : lds[i_ct[cc] + k * 3]; };
-    auto clo = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.lb[cc % NAX][k] : lds[i_ct[cc] + k * 3 + 1]; };
-    auto chi = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.ub[cc % NAX][k] : lds[i_ct[cc] + k * 3 + 2]; };
+    // UNI: every axis has the same step size and box on the slots past the position (the host
+    // checks), so those constants are scalars too; only the position slot goes through the table
+    auto crho = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.rho_box[cc % NAX][k] : (UNI && k >= 1) ? P.rho_box[0][k] : lds[i_ct[cc] + k * 3]; };
+    auto clo = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.lb[cc % NAX][k] : (UNI && k >= 1) ? P.lb[0][k] : lds[i_ct[cc] + k * 3 + 1]; };
+    auto chi = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.ub[cc % NAX][k] : (UNI && k >= 1) ? P.ub[0][k] : lds[i_ct[cc] + k * 3 + 2]; };
     // Step sizes and box bounds of the thread's cells, in registers when few cells per thread leave
     // room: the LDS pipe is the busiest unit of the rhs and projection phases.  Slots 1.. have
     // symmetric bounds in every stage (the host checks); slot 0 keeps both ends (altitude floor).
@@ -1688,10 +1690,10 @@ size_t admm_lds_bytes(const StageDev &P)
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, bool UNI = false>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why)
 {
-    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT, KPART>;
+    auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT, KPART, UNI>;
     if (KSREG == 0 && P.ring != PDT) { *why = "internal: ring depth of the stage and of the kernel variant differ"; return hipErrorInvalidValue; }
     if ((P.kpart == 2) != (KPART == 2)) { *why = "internal: k-range parts of the stage and of the kernel variant differ"; return hipErrorInvalidValue; }
     if ((P.sm != 0) != SM || (P.ql != 0) != QL) { *why = "internal: box-row form of the stage and of the kernel variant differ"; return hipErrorInvalidValue; }   // the LDS layout follows P.ql
@@ -1806,7 +1808,16 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
 #if TG_HAS(2)
             // (step-major cells, SMJ with MAXC = 6, were measured at N = 50: 20350 against 20000 cycles
             // per iteration -- the per-axis constants then travel through spilled scalar registers)
-            if (P.sm && P.ql && P.lr_ukp == 1) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s, why);
+            if (P.sm && P.ql && P.lr_ukp == 1) {
+                // step sizes and boxes past the position slot equal on all axes (the usual case:
+                // one speed and one acceleration limit): read as scalars instead of through the table
+                bool uni = true;
+                for (int ax = 1; ax < P.nax; ax++)
+                    for (int k = 1; k <= P.D; k++)
+                        uni = uni && P.rho_box[ax][k] == P.rho_box[0][k] && P.lb[ax][k] == P.lb[0][k] && P.ub[ax][k] == P.ub[0][k];
+                if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1, false, kRingDepth, 1, true>(P, a, s, why);
+                return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s, why);
+            }
 #endif
 #if TG_HAS(3)
             return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(plain, a, s, why);
