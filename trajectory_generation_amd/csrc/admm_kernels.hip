@@ -1789,11 +1789,18 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     plain.sm = 0; plain.ql = 0;
     if (admm_lds_bytes(plain) > kLdsLimit) { *why = "horizon too long: iterates do not fit the 160 KiB LDS"; return hipErrorInvalidValue; }
     single.sm = 0; single.ql = 0;
+    // step sizes and boxes past the position slot equal on all axes (the usual case: one speed and
+    // one acceleration limit): the UNI variants read them as scalars instead of per-lane values
+    bool uni = true;
+    for (int ax = 1; ax < P.nax; ax++)
+        for (int k = 1; k <= P.D; k++)
+            uni = uni && P.rho_box[ax][k] == P.rho_box[0][k] && P.lb[ax][k] == P.lb[0][k] && P.ub[ax][k] == P.ub[0][k];
     if (P.lr && P.lr_np == 4) {
         // low-rank operators with register-resident fragments (6-DOF, short horizons)
         if (P.D == 2 && P.nax == 3 && !P.mixed && sym && sep && needc <= 2 && needi <= 1 && needj <= 1 && fits(16) &&
             P.lr_crb == 1 && P.lr_uk == 1) {
 #if TG_HAS(1)
+            if (uni) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true, false, false, 2, false, kRingDepth, 1, true>(plain, a, s, why);
             return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(plain, a, s, why);
 #endif
         }
@@ -1809,12 +1816,6 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
             // (step-major cells, SMJ with MAXC = 6, were measured at N = 50: 20350 against 20000 cycles
             // per iteration -- the per-axis constants then travel through spilled scalar registers)
             if (P.sm && P.ql && P.lr_ukp == 1) {
-                // step sizes and boxes past the position slot equal on all axes (the usual case:
-                // one speed and one acceleration limit): read as scalars instead of through the table
-                bool uni = true;
-                for (int ax = 1; ax < P.nax; ax++)
-                    for (int k = 1; k <= P.D; k++)
-                        uni = uni && P.rho_box[ax][k] == P.rho_box[0][k] && P.lb[ax][k] == P.lb[0][k] && P.ub[ax][k] == P.ub[0][k];
                 if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1, false, kRingDepth, 1, true>(P, a, s, why);
                 return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s, why);
             }
