@@ -1821,6 +1821,7 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
             }
 #endif
 #if TG_HAS(3)
+            if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, false, false, 2, false, kRingDepth, 1, true>(plain, a, s, why);
             return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(plain, a, s, why);
 #endif
         }
