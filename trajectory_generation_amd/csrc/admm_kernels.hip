@@ -108,7 +108,7 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 // UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
 //        operator's own are zero).
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, bool UNI = false>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, int UNI = 0>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
 {
     constexpr int S = D + 1;
@@ -238,6 +238,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     int i_prev2[KPART == 2 ? MAXC : 1];   // the same in VX2
     int i_wnext[MAXC];   // absolute index of the next cell's dynamics-row w (or ZERO)
     int i_ct[MAXC];      // absolute index of the cell's axis in the constant table
+    bool lastax[MAXC];   // the cell is on the last axis
     int i_bg[MAXC];      // absolute index of the cell's dynamics-row bound (BGT at step 0, else ZERO)
     int i_mx[MIXED ? MAXC : 1];     // absolute index of the step's mixed-row w (or ZERO)
     bool axis0[MIXED ? MAXC : 1];
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         if constexpr (KPART == 2) i_prev2[cc] = (act && st > 0) ? i_prev[cc] + X2 : ZERO + t;
         i_wnext[cc] = (act && st < N) ? WEQ + ((c + 1) * D) * 16 + t : ZERO + t;
         i_ct[cc] = CTAB + ax * S * 3;
+        lastax[cc] = ax == NAX - 1;
         i_bg[cc] = (act && st == 0) ? BGT + ax * D * 16 + t : ZERO + t;
         if (MIXED) {
             i_mx[cc] = (act && st >= 1) ? WMX + st * 6 * 16 + t : ZERO + t;
@@ -276,11 +278,18 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 
     // per-axis constants of cell slot cc: scalar kernel arguments when the slot's axis is known at
     // compile time, else the LDS table
-    // UNI: every axis has the same step size and box on the slots past the position (the host
-    // checks), so those constants are scalars too; only the position slot goes through the table
-    auto crho = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.rho_box[cc % NAX][k] : (UNI && k >= 1) ? P.rho_box[0][k] : lds[i_ct[cc] + k * 3]; };
-    auto clo = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.lb[cc % NAX][k] : (UNI && k >= 1) ? P.lb[0][k] : lds[i_ct[cc] + k * 3 + 1]; };
-    auto chi = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.ub[cc % NAX][k] : (UNI && k >= 1) ? P.ub[0][k] : lds[i_ct[cc] + k * 3 + 2]; };
+    // UNI >= 1: every axis has the same step size and box on the slots past the position (the host
+    // checks), so those constants are scalars too and only the position slot goes through the table.
+    // UNI == 2: on the position slot the axes differ only in the last one's step size and lower
+    // bound (the altitude floor): a select between two scalars on whether the cell is on that axis.
+    auto crho = [&](int cc, int k) __attribute__((always_inline)) -> double {
+        return CAX ? P.rho_box[cc % NAX][k] : (UNI >= 1 && k >= 1) ? P.rho_box[0][k]
+             : UNI == 2 ? (lastax[cc] ? P.rho_box[NAX - 1][0] : P.rho_box[0][0]) : lds[i_ct[cc] + k * 3]; };
+    auto clo = [&](int cc, int k) __attribute__((always_inline)) -> double {
+        return CAX ? P.lb[cc % NAX][k] : (UNI >= 1 && k >= 1) ? P.lb[0][k]
+             : UNI == 2 ? (lastax[cc] ? P.lb[NAX - 1][0] : P.lb[0][0]) : lds[i_ct[cc] + k * 3 + 1]; };
+    auto chi = [&](int cc, int k) __attribute__((always_inline)) -> double {
+        return CAX ? P.ub[cc % NAX][k] : (UNI >= 1 && k >= 1) ? P.ub[0][k] : UNI == 2 ? P.ub[0][0] : lds[i_ct[cc] + k * 3 + 2]; };
     // Step sizes and box bounds of the thread's cells, in registers when few cells per thread leave
     // room: the LDS pipe is the busiest unit of the rhs and projection phases.  Slots 1.. have
     // symmetric bounds in every stage (the host checks); slot 0 keeps both ends (altitude floor).
@@ -1690,7 +1699,7 @@ size_t admm_lds_bytes(const StageDev &P)
 }
 
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR = false,
-          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, bool UNI = false>
+          bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, int UNI = 0>
 static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream_t s, const char **why)
 {
     auto kern = admm_kernel<NT, D, NAX, MIXED, MAXC, MAXIT, PAIR, KSREG, SEP, LR, SM, QL, UK, SMJ, PDT, KPART, UNI>;
@@ -1791,16 +1800,19 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
     single.sm = 0; single.ql = 0;
     // step sizes and boxes past the position slot equal on all axes (the usual case: one speed and
     // one acceleration limit): the UNI variants read them as scalars instead of per-lane values
-    bool uni = true;
-    for (int ax = 1; ax < P.nax; ax++)
+    bool uni = true, uni0 = true;   // uni0: on the position slot only the last axis's step size and lower bound differ
+    for (int ax = 1; ax < P.nax; ax++) {
         for (int k = 1; k <= P.D; k++)
             uni = uni && P.rho_box[ax][k] == P.rho_box[0][k] && P.lb[ax][k] == P.lb[0][k] && P.ub[ax][k] == P.ub[0][k];
+        uni0 = uni0 && P.ub[ax][0] == P.ub[0][0] &&
+               (ax == P.nax - 1 || (P.rho_box[ax][0] == P.rho_box[0][0] && P.lb[ax][0] == P.lb[0][0]));
+    }
     if (P.lr && P.lr_np == 4) {
         // low-rank operators with register-resident fragments (6-DOF, short horizons)
         if (P.D == 2 && P.nax == 3 && !P.mixed && sym && sep && needc <= 2 && needi <= 1 && needj <= 1 && fits(16) &&
             P.lr_crb == 1 && P.lr_uk == 1) {
 #if TG_HAS(1)
-            if (uni) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true, false, false, 2, false, kRingDepth, 1, true>(plain, a, s, why);
+            if (uni) return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true, false, false, 2, false, kRingDepth, 1, 1>(plain, a, s, why);
             return launch_admm_t<512, 2, 3, false, 2, 1, true, 16, true, true>(plain, a, s, why);
 #endif
         }
@@ -1816,12 +1828,13 @@ hipError_t launch_admm(const StageDev &P, const BatchArgs &a, hipStream_t s, con
             // (step-major cells, SMJ with MAXC = 6, were measured at N = 50: 20350 against 20000 cycles
             // per iteration -- the per-axis constants then travel through spilled scalar registers)
             if (P.sm && P.ql && P.lr_ukp == 1) {
-                if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1, false, kRingDepth, 1, true>(P, a, s, why);
+                if (uni && uni0) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1, false, kRingDepth, 1, 2>(P, a, s, why);
+                if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1, false, kRingDepth, 1, 1>(P, a, s, why);
                 return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, true, true, 1>(P, a, s, why);
             }
 #endif
 #if TG_HAS(3)
-            if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, false, false, 2, false, kRingDepth, 1, true>(plain, a, s, why);
+            if (uni) return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true, false, false, 2, false, kRingDepth, 1, 1>(plain, a, s, why);
             return launch_admm_t<512, 2, 3, false, 5, 3, true, 0, false, true>(plain, a, s, why);
 #endif
         }
