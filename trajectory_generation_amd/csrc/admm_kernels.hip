@@ -290,6 +290,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
              : UNI == 2 ? (lastax[cc] ? P.lb[NAX - 1][0] : P.lb[0][0]) : lds[i_ct[cc] + k * 3 + 1]; };
     auto chi = [&](int cc, int k) __attribute__((always_inline)) -> double {
         return CAX ? P.ub[cc % NAX][k] : (UNI >= 1 && k >= 1) ? P.ub[0][k] : UNI == 2 ? P.ub[0][0] : lds[i_ct[cc] + k * 3 + 2]; };
+    // the termination check reads the table (it runs once per 25 iterations and has no registers to spare)
+    auto crho_t = [&](int cc, int k) __attribute__((always_inline)) -> double { return CAX ? P.rho_box[cc % NAX][k] : lds[i_ct[cc] + k * 3]; };
     // Step sizes and box bounds of the thread's cells, in registers when few cells per thread leave
     // room: the LDS pipe is the busiest unit of the rhs and projection phases.  Slots 1.. have
     // symmetric bounds in every stage (the host checks); slot 0 keeps both ends (altitude floor).
@@ -1157,7 +1159,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         double lo = 0.0, hi = 0.0;
-                        if constexpr (SM) box_of(cc, k, lo, hi);
+                        if constexpr (SM) {
+                            if (CAX || REGC) box_of(cc, k, lo, hi);
+                            else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+                        }
                         zy_of(cc, k, lo, hi, zc[k], yc[k]);
                     }
                     double yn[D], mixc[3] = {0.0, 0.0, 0.0};
@@ -1174,7 +1179,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int l = 0; l < D; l++) {
                         const double px = l == 0 ? pdiag * x[cc][0] : 0.0;
-                        double aty = crho(cc, l) * yc[l] - rho_eq * yg[cc][l];
+                        double aty = crho_t(cc, l) * yc[l] - rho_eq * yg[cc][l];
 #pragma unroll
                         for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
                         if (MIXED && l >= 1) aty += mixc[l];
@@ -1190,7 +1195,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             const double up = st < N - 1 ? xin[(D + S) * 16] : x[cc][D];
                             px += P.smooth * ((x[cc][D] - um) + (x[cc][D] - up));
                         }
-                        const double aty = crho(cc, D) * yc[D] + dt * yn[D - 1];
+                        const double aty = crho_t(cc, D) * yc[D] + dt * yn[D - 1];
                         m_rd = fmax(m_rd, fabs(px + aty));
                         m_px = fmax(m_px, fabs(px));
                         m_aty = fmax(m_aty, fabs(aty));
