@@ -1152,6 +1152,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     const int ax = axis_of(c), st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
                     const double *xpr = lds + i_prev[cc];
+                    // x of the cell read back from VX: the registers that held it are free from the
+                    // copy above to the end of the exit code (the check is the one place short of them)
+                    double xc[S];
+#pragma unroll
+                    for (int k = 0; k < S; k++) xc[k] = xin[k * 16];
                     double pdiag = 0.0;
 #pragma unroll
                     for (int k = 0; k < NAX; k++) if (ax == k) pdiag = P.pdiag[k];
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     // dual residual P x + q + A' y on the state slots
 #pragma unroll
                     for (int l = 0; l < D; l++) {
-                        const double px = l == 0 ? pdiag * x[cc][0] : 0.0;
+                        const double px = l == 0 ? pdiag * xc[0] : 0.0;
                         double aty = crho_t(cc, l) * yc[l] - rho_eq * yg[cc][l];
 #pragma unroll
                         for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
@@ -1189,11 +1194,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         m_aty = fmax(m_aty, fabs(aty));
                     }
                     if (st < N) { // input slot: P = r I + smooth * D'D (first difference of inputs)
-                        double px = P.r * x[cc][D];
+                        double px = P.r * xc[D];
                         if (P.smooth != 0.0) {
-                            const double um = st > 0 ? xpr[D * 16] : x[cc][D];
-                            const double up = st < N - 1 ? xin[(D + S) * 16] : x[cc][D];
-                            px += P.smooth * ((x[cc][D] - um) + (x[cc][D] - up));
+                            const double um = st > 0 ? xpr[D * 16] : xc[D];
+                            const double up = st < N - 1 ? xin[(D + S) * 16] : xc[D];
+                            px += P.smooth * ((xc[D] - um) + (xc[D] - up));
                         }
                         const double aty = crho_t(cc, D) * yc[D] + dt * yn[D - 1];
                         m_rd = fmax(m_rd, fabs(px + aty));
@@ -1204,15 +1209,15 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         if (k < D || st < N) {
-                            m_rp = fmax(m_rp, fabs(x[cc][k] - zc[k]));
-                            m_ax = fmax(m_ax, fabs(x[cc][k]));
+                            m_rp = fmax(m_rp, fabs(xc[k] - zc[k]));
+                            m_ax = fmax(m_ax, fabs(xc[k]));
                             m_z = fmax(m_z, fabs(zc[k]));
                         }
                     }
                     // ... dynamics rows ...
 #pragma unroll
                     for (int k = 0; k < D; k++) {
-                        double axv = -x[cc][k];
+                        double axv = -xc[k];
 #pragma unroll
                         for (int l = k; l < D; l++) axv += chain_coef<D>(k, l, dt, c2) * xpr[l * 16];
                         if (k == D - 1) axv += dt * xpr[D * 16];
@@ -1291,8 +1296,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         for (int k = 0; k < NAX; k++) if (ax == k) { xoff = P.X_off[k]; uoff = P.U_off[k]; }
 #pragma unroll
                         for (int k = 0; k < D; k++)
-                            a.X[(size_t)(st * P.X_stride + xoff + k * P.X_slot) * a.ld + inst] = x[cc][k];
-                        if (st < N) a.U[(size_t)(st * P.U_stride + uoff) * a.ld + inst] = x[cc][D];
+                            a.X[(size_t)(st * P.X_stride + xoff + k * P.X_slot) * a.ld + inst] = vx[i_var[cc] + k * 16];
+                        if (st < N) a.U[(size_t)(st * P.U_stride + uoff) * a.ld + inst] = vx[i_var[cc] + D * 16];
                     }
                 }
                 if (g == 0) {
@@ -1312,7 +1317,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
 #pragma unroll
                             for (int k = 0; k < S; k++) {
-                                a.warm[w0 + (size_t)k * a.ldw] = x[cc][k];
+                                a.warm[w0 + (size_t)k * a.ldw] = vx[i_var[cc] + k * 16];
                                 a.warm[w0 + (size_t)(n_int + k) * a.ldw] = zb[cc][k];   // SM: s
                                 if constexpr (!SM) a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] = yb[cc][k];
                             }
@@ -1340,6 +1345,12 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 }
             }
             CSTAMP(4);
+            // x back into its registers (VX has held it since the start of the check)
+#pragma unroll
+            for (int cc = 0; cc < MAXC; cc++) {
+#pragma unroll
+                for (int k = 0; k < S; k++) x[cc][k] = vx[i_var[cc] + k * 16];
+            }
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
