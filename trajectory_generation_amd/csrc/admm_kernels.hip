@@ -1132,7 +1132,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                 for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
 #pragma unroll
-                for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * yg[cc][k];
+                for (int k = 0; k < D; k++) lds[WEQ + (cw * D + k) * 16 + t] = yg[cc][k];   // as it is: read back below
             }
             if (MIXED) {
 #pragma unroll
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                     double yn[D], mixc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int k = 0; k < D; k++) yn[k] = lds[i_wnext[cc] + k * 16];
+                    for (int k = 0; k < D; k++) yn[k] = rho_eq * lds[i_wnext[cc] + k * 16];
                     if (MIXED) {
                         const double *wm = lds + i_mx[cc];
                         const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
@@ -1184,7 +1184,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                     for (int l = 0; l < D; l++) {
                         const double px = l == 0 ? pdiag * xc[0] : 0.0;
-                        double aty = crho_t(cc, l) * yc[l] - rho_eq * yg[cc][l];
+                        double aty = crho_t(cc, l) * yc[l] - rho_eq * lds[WEQ + (c * D + l) * 16 + t];
 #pragma unroll
                         for (int k = 0; k <= l; k++) aty += chain_coef<D>(k, l, dt, c2) * yn[k];
                         if (MIXED && l >= 1) aty += mixc[l];
@@ -1325,7 +1325,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                             for (int k = 0; k < D; k++) {
                                 a.warm[e0 + (size_t)k * a.ldw] = lds[i_bg[cc] + k * 16];
-                                a.warm[e0 + (size_t)(ncell * D + k) * a.ldw] = yg[cc][k];
+                                a.warm[e0 + (size_t)(ncell * D + k) * a.ldw] = lds[WEQ + (c * D + k) * 16 + t];
                             }
                         }
                     }
@@ -1350,6 +1350,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             for (int cc = 0; cc < MAXC; cc++) {
 #pragma unroll
                 for (int k = 0; k < S; k++) x[cc][k] = vx[i_var[cc] + k * 16];
+            }
+            // and y of the dynamics rows, from WEQ
+#pragma unroll
+            for (int cc = 0; cc < MAXC; cc++) {
+                const int cw = cell_of(cc);
+#pragma unroll
+                for (int k = 0; k < D; k++) yg[cc][k] = lds[WEQ + (cw * D + k) * 16 + t];
             }
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
