@@ -90,7 +90,8 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 // LDS regions, all [rows][16 instances] of doubles, addressed by absolute double index:
 //   V0  rhs of the linear solve            n_int + S rows (the last S rows take the writes of
 //   VX  xt, and x during a check           n_int + S rows  a thread's unused cell slots)
-//   WEQ w = rho z - y of the dynamics rows ncell*D + D rows
+//   VX2 KPART == 2: second partial xt      n_int + S rows
+//   WEQ w = rho z - y of the dynamics rows ncell*D + D rows (their y itself during a check)
 //   WMX the same for the XY mixed rows     6 (N+1) + 6 rows
 //   SB  LR: C r of every block             blocks * sb_rows rows
 //   ZERO rows that stay zero: what a neighbour read returns past either end of the horizon
@@ -107,6 +108,14 @@ template <int D> __device__ __forceinline__ double chain_coef(int k, int l, doub
 //        per-axis step sizes and bounds are scalar operands instead of LDS reads.
 // UK:    k-steps of U_I per tile in the streamed low-rank form (P.lr_ukp; fragments past the
 //        operator's own are zero).
+// PDT:   depth of the fragment ring of the streamed variants (an item is a whole number of rounds).
+// KPART: 2 = register-resident dense variant in which some row blocks are split in two items of half
+//        the k range each (fewer row blocks than waves); the second halves' products go to VX2.
+// UNI:   how the step sizes and box bounds of a cell reach the vector phases when the cell's axis is
+//        not known at compile time: 0 = per-axis LDS table; 1 = the slots past the position are
+//        scalars (all axes share them), the position slot through the table; 2 = the position slot
+//        too, as a select between two scalars (only the last axis differs: the altitude floor).
+//        The host checks the conditions at launch.
 template <int NT, int D, int NAX, bool MIXED, int MAXC, int MAXIT, bool PAIR, int KSREG, bool SEP, bool LR,
           bool SM = false, bool QL = false, int UK = 2, bool SMJ = false, int PDT = kRingDepth, int KPART = 1, int UNI = 0>
 __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchArgs a)
