@@ -41,3 +41,18 @@ def test_every_horizon_matches_the_oracle(oracle):
         forms.add(("12state",) + tuple(e12.kernel_info("xy")))
     oracle.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
     assert len(forms) >= 20      # many different operator forms / MFMA counts were exercised
+
+
+def test_random_model_parameters_match_the_oracle():
+    """Thirty random parameter sets per family (weights over two decades, dt, limits that differ
+    per axis, smoothing on and off, horizons 3 .. 50): every solve launches -- whichever kernel
+    variant, constant path and operator form the parameters select -- and agrees with the CPU
+    oracle in the engine's mode (tools/param_sweep.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "param_sweep.py")], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600, cwd=root)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "problems: 0" in out, out[-3000:]

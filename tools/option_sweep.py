@@ -31,3 +31,4 @@ for N in range(1, 51):
                     print("N %d %s smooth %d %s: %d iteration counts differ from default" % (N, fam, smooth, name, d), flush=True); bad += 1
     print("N", N, "done", flush=True)
 print("problems:", bad)
+sys.exit(1 if bad else 0)

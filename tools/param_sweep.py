@@ -57,3 +57,4 @@ for trial in range(30):
     except Exception as ex:
         print("12st  trial", trial, N, "FAIL", ex, flush=True); bad += 1
 print("problems:", bad)
+sys.exit(1 if bad else 0)
