@@ -153,6 +153,16 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         const int c = g + kStride * cc;
         return c < ncell ? c : ncell;
     };
+    // The same for the code that runs once per check (residuals, exit, refill): gq equals g but is
+    // made opaque at every check, so that what this code derives from it (cell numbers, steps,
+    // offsets into the batch arrays) is computed where it is used instead of being kept across the
+    // iterations, where there is no register for it and it would live in scratch memory.
+    int gq = g;
+    auto cell_q = [&](int cc) __attribute__((always_inline)) -> int {
+        if (CAX) { const int st = gq + kStride * (cc / NAX); return st <= N ? (cc % NAX) * N1 + st : ncell; }
+        const int c = gq + kStride * cc;
+        return c < ncell ? c : ncell;
+    };
 
     // register-resident operator fragments: requested first, so that their L2 latency passes
     // behind the set-up below
@@ -343,7 +353,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         double refv[MAXC];
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
-            const int c = cell_of(cc);
+            const int c = cell_q(cc);
             const bool act = c < ncell;
             const int ax = act ? axis_of(c) : 0;
             const int st = act ? c - ax * N1 : 0;
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         }
 #pragma unroll
         for (int cc = 0; cc < MAXC; cc++) {
-            const int c = cell_of(cc);
+            const int c = cell_q(cc);
             const bool act = c < ncell;
             const int ax = act ? axis_of(c) : 0;
             const int st = act ? c - ax * N1 : 0;
@@ -1101,6 +1111,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- termination check
         {
             CSTAMP(0);
+            asm volatile("" : "+v"(gq));
             __syncthreads();
             // ||A' delta_y||_inf: own part + the next step's dynamics rows + the mixed rows
             double m_atdy = 0.0;
@@ -1136,7 +1147,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // x -> VX, y of the dynamics / mixed rows -> WEQ / WMX (restored below)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = cell_of(cc);
+                const int cw = cell_q(cc);
                 double *xo = vx + i_var[cc];
 #pragma unroll
                 for (int k = 0; k < S; k++) xo[k * 16] = x[cc][k];
@@ -1156,7 +1167,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             double m_rp = 0, m_ax = 0, m_z = 0, m_rd = 0, m_px = 0, m_aty = 0;
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int c = cell_of(cc);
+                const int c = cell_q(cc);
                 if (c < ncell) {
                     const int ax = axis_of(c), st = c - ax * N1;
                     const double *xin = vx + i_var[cc];
@@ -1297,7 +1308,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 const bool wr = conv || !pinf;
 #pragma unroll
                 for (int cc = 0; cc < MAXC; cc++) {
-                    const int c = cell_of(cc);
+                    const int c = cell_q(cc);
                     if (wr && c < ncell) {
                         const int ax = axis_of(c), st = c - ax * N1;
                         int xoff = 0, uoff = 0;
@@ -1317,7 +1328,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (a.warm_out) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
-                        const int c = cell_of(cc);
+                        const int c = cell_q(cc);
                         if (c < ncell) {
                             const int ax = axis_of(c), st = c - ax * N1;
                             int abase = 0;
@@ -1363,14 +1374,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // and y of the dynamics rows, from WEQ
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = cell_of(cc);
+                const int cw = cell_q(cc);
 #pragma unroll
                 for (int k = 0; k < D; k++) yg[cc][k] = lds[WEQ + (cw * D + k) * 16 + t];
             }
             // WEQ / WMX held y during the check: restore w = rho (z - y/rho)
 #pragma unroll
             for (int cc = 0; cc < MAXC; cc++) {
-                const int cw = cell_of(cc);
+                const int cw = cell_q(cc);
 #pragma unroll
                 for (int k = 0; k < D; k++)
                     lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (lds[i_bg[cc] + k * 16] - yg[cc][k]);
