@@ -36,7 +36,7 @@ print("cycles per iteration (kernel info %s)" % (eng.kernel_info() if model == "
 print("wave " + " ".join("%8s" % n for n in names) + "    total")
 for w in range(2):
     print("%4d " % (4 * w) + " ".join("%8.0f" % v for v in acc[w]) + " %8.0f" % acc[w].sum())
-print("cycles per termination check: barrier | x, y to LDS | residual loops | reductions | exit writes | restore w | refill + load")
+print("cycles per termination check: barrier, A' dy, x and y to LDS | residual loops | reductions | exit writes | restore x, y, w | refill + load")
 for w in range(2):
     n = max(ck[w][7], 1.0)
-    print("%4d " % (4 * w) + " ".join("%8.0f" % (v / n) for v in ck[w][:7]) + "   total %8.0f  (%d checks)" % (ck[w][:7].sum() / n, n))
+    print("%4d " % (4 * w) + " ".join("%8.0f" % (v / n) for v in ck[w][:6]) + "   total %8.0f  (%d checks)" % (ck[w][:6].sum() / n, n))
