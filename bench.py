@@ -42,7 +42,7 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "mpc_6dof_B262144_N50"
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD at 2.4 GHz)
 FP64_MFMA_SUSTAINED_TFLOPS = 75.7   # tools/microbench/mfma_valu_overlap.hip on the box: register-only MFMA, two chains per SIMD
-PIPELINE = {"mpc_12state_B4096_N20": 6, "mpc_6dof_B4096_N20": 4,
+PIPELINE = {"mpc_12state_B4096_N20": 6, "mpc_6dof_B4096_N20": 4, "mpc_6dof_B32768_N50": 3,
             "rollout_12state_B8192_N20": 4}   # closed loop: sub-fleets, each on its own stream   # default batches in flight (--pipeline 0)
 MIN_TIMED_S = 0.5              # shorter regions are repeated until this much has been timed
 PROFILE_ROUND = "r02"
@@ -206,6 +206,13 @@ def main():
     # queue run in turn: with four to six handles in flight that leaves some of them behind a slow
     # launch.  Eight queues give every handle its own; read by the runtime when it starts.
     depth = args.pipeline if args.pipeline > 0 else PIPELINE.get(args.workload, 1)
+    # The fixed-total workload on several GPUs: a rank's share ends with the chip waiting for the
+    # share's slowest instance (300 iterations = 2.4 ms at N = 50, whatever the share's size), which
+    # weighs the more the smaller the share is; the next batches run meanwhile.  One GPU with the
+    # whole batch keeps one in flight: there the tail is a few per cent.
+    ranks_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.pipeline <= 0 and args.workload in WORKLOADS and WORKLOADS[args.workload][4] == "total" and ranks_env > 1:
+        depth = 3 if WORKLOADS[args.workload][1] // ranks_env <= 65536 else 2
     if depth > 1:
         os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
