@@ -429,7 +429,7 @@ def main():
         "scaling": "strong" if split == "total" else "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": args.workload, "instances_total": int(total_inst), "instances_rank0": B, "horizon_N": N,
-                   "horizon_limit": "N <= 50 (iterates of 16 instances stay in the 160 KiB of LDS)",
+                   "horizon_limit": "6-DOF N <= 81, 12-state N <= 60 (iterates of 16 instances stay in the 160 KiB of LDS)",
                    "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check,
                    "check_fine": args.check_fine, "grid_cap": args.grid_cap, "lowrank": args.lowrank, "hard_first": args.hard_first,
                    "smoothing": bool(args.smoothing), "inputs": "stress" if args.stress else "seeded",

@@ -135,7 +135,10 @@ struct DevStage {
                 const bool in_registers = (six && cells <= 2 && dev.ks <= 16) || (!six && !xy && cells <= 1 && dev.ks <= 21);
                 regs_dense = in_registers;
                 const int dense_mfma = dev.nrb * dev.ks, lr_mfma = sp.lr_crb * dev.ks + dev.nrb * (4 + sp.lr_uk);
-                dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
+                // (the streamed low-rank 6-DOF variant is compiled for five cells per thread: N <= 52;
+                // longer horizons take the dense variant with eight)
+                const bool lr_compiled = !six || cells <= 5;
+                dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && lr_compiled && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
                 dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
                 // streamed low-rank form: C r as two partial sums (the k range of a row block of C is
                 // cut in two items, so that the first stage spreads evenly over the waves)
@@ -214,7 +217,7 @@ struct DevStage {
         // eight waves into pair waves and single waves the items go longest first onto the least
         // loaded wave of their kind; the waves are then matched to SIMDs heaviest with lightest
         // (waves w and w + 4 share SIMD w % 4); the split with the lightest heaviest SIMD wins.
-        auto deal = [&](const std::vector<Item> &items, std::vector<Item> *out) -> bool {
+        auto deal = [&](const std::vector<Item> &items, std::vector<Item> *out, int limit) -> bool {
             std::vector<Item> kind[2];
             for (const Item &it : items) kind[dev.grp_cnt[it.grp] == 2 ? 1 : 0].push_back(it);
             for (auto &v : kind) std::stable_sort(v.begin(), v.end(), [](const Item &x, const Item &y) { return x.cost > y.cost; });
@@ -232,7 +235,7 @@ struct DevStage {
                     for (const Item &it : kind[k]) {
                         int w = lo;
                         for (int c = lo + 1; c < hi; c++) if (load[c] < load[w]) w = c;
-                        if ((int)bins[w].size() >= kMaxItems) { ok = false; break; }
+                        if ((int)bins[w].size() >= limit) { ok = false; break; }
                         bins[w].push_back(it); load[w] += it.cost;
                     }
                 }
@@ -281,7 +284,9 @@ struct DevStage {
                 }
                 for (int rb = 0; rb < (dev.lr ? dev.nrb : 0); rb++) tiles.push_back({gi, rb, cnt * (4 + dev.lr_ukp), 0, 0, 0});
             }
-            if (!deal(items, dealt1) || !deal(tiles, dealt2))
+            // no compiled kernel variant takes more than four items per wave and stage: a split within
+            // that is preferred to a better balanced one beyond it
+            if (!(deal(items, dealt1, 4) || deal(items, dealt1, kMaxItems)) || !(deal(tiles, dealt2, 4) || deal(tiles, dealt2, kMaxItems)))
                 return fail(TG_E_ARG, "horizon too long: too many MFMA row blocks");
         }
         mfma_streamed = 0;
