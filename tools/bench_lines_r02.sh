@@ -14,6 +14,8 @@ run n50_default --steps 20 --warmup 3
 run n50_gridcap_off --steps 10 --no-cpu-baseline --grid-cap -1
 run n50_dense --steps 10 --no-cpu-baseline --lowrank -1
 run n50_B32768 --workload mpc_6dof_B32768_N50 --steps 40 --no-cpu-baseline
+run n50_B32768_serial --workload mpc_6dof_B32768_N50 --steps 40 --pipeline 1 --no-cpu-baseline
+run n50_two_in_flight --steps 10 --pipeline 2 --no-cpu-baseline
 run n20_6dof --workload mpc_6dof_B4096_N20 --steps 200
 run n20_6dof_serial --workload mpc_6dof_B4096_N20 --steps 200 --pipeline 1 --no-cpu-baseline
 run n20_6dof_fine5 --workload mpc_6dof_B4096_N20 --steps 200 --pipeline 1 --check-fine 5 --no-cpu-baseline
