@@ -61,6 +61,18 @@ def test_bench_self_launches_its_ranks():
     assert d["config"]["instances_total"] == 2 * 4096 and d["solved_frac"] == 1.0
 
 
+def test_bench_small_batch_line_carries_the_finer_check_schedule_as_a_second_figure():
+    """mpc_6dof_B4096_N20 keeps OSQP's schedule of checks for its value; the figure with convergence
+    also tested every 5 iterations is a second key."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2",
+                        "--workload", "mpc_6dof_B4096_N20", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
+    d = _last_json(r.stdout.decode())
+    cf = d["check_fine_5"]
+    assert d["config"]["check_fine"] == 0 and cf["solved_frac"] == 1.0 and cf["value"] > 1e6
+    assert cf["iters_mean"] <= d["iters_mean"] and cf["iters_max"] <= d["iters_max"]
+
+
 def test_bench_two_ranks_shard_the_instances():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
