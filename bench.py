@@ -351,7 +351,7 @@ def main():
     iters = np.concatenate([view(hb, "iters") for hb in (bufs if closed else bufs[:1])], axis=1)
     status = np.concatenate([view(hb, "status") for hb in (bufs if closed else bufs[:1])], axis=1)
     stats = torch.tensor([float(iters.sum()), float((status == 1).all(0).sum()), float(B),
-                          float((status == -2).any(0).sum()), float((status == -3).any(0).sum())],
+                          float(np.isin(status, (-2, 2, 3)).any(0).sum()), float((status == -3).any(0).sum())],   # 2 / 3: OSQP's inaccurate verdicts at max_iter
                          dtype=torch.float64, device=red_dev)
     # OSQP's residuals at the check that ended each solve (handle 0's last batch), maxima over the
     # solved instances
@@ -470,7 +470,7 @@ def main():
         # of its solve did not end "solved" (the plant then follows the last plan it received)
         hs = np.concatenate([hh[0].cpu().numpy().reshape(args.steps, -1, hb["ld"])[:, :, :Bh] for hh, hb in zip(hist, bufs)], axis=2)
         hi = np.concatenate([hh[1].cpu().numpy().reshape(args.steps, -1, hb["ld"])[:, :, :Bh] for hh, hb in zip(hist, bufs)], axis=2)
-        failed = (hs != 1).any(1).mean(1); hit = (hs == -2).any(1).mean(1); infeas = (hs == -3).any(1).mean(1)
+        failed = (hs != 1).any(1).mean(1); hit = np.isin(hs, (-2, 2, 3)).any(1).mean(1); infeas = (hs == -3).any(1).mean(1)
         out["closed_loop"] = {
             "steps": args.steps, "vehicles_rank0": B,
             "failed_frac_per_step": {"mean": float(failed.mean()), "max": float(failed.max()), "last": float(failed[-1])},

@@ -18,8 +18,10 @@
  *     so that one wavefront reads 64 consecutive instances of one row
  *   - host-side batched arrays are instance-major (one reference-style vector per
  *     instance, back to back), exactly the vectors the reference's methods take
- *   - status per instance: 1 solved, -2 max_iter reached, -3 primal infeasible
- *     detected (OSQP status numbering, what osqp-eigen's solve() turns into the bool)
+ *   - status per instance: 1 solved, -2 max_iter reached, -3 primal infeasible detected, and
+ *     OSQP's two verdicts of its last test at max_iter with tenfold tolerances: 2 solved
+ *     inaccurate, 3 primal infeasible inaccurate (OSQP status numbering; osqp-eigen's solve(),
+ *     hence mpcLoop(), is true for 1 only)
  */
 #ifndef TG_MPC_H
 #define TG_MPC_H
@@ -31,7 +33,8 @@ extern "C" {
 #define TG_INFTY 1e30 /* OsqpEigen::INFTY, mpc_6dof.cpp:306-308 */
 
 enum { TG_OK = 0, TG_E_ARG = -1, TG_E_HIP = -2, TG_E_STATE = -3, TG_E_NUMERIC = -4 };
-enum { TG_SOLVED = 1, TG_MAX_ITER = -2, TG_PRIMAL_INFEASIBLE = -3, TG_UNSOLVED = -10 };
+enum { TG_SOLVED = 1, TG_SOLVED_INACCURATE = 2, TG_PRIMAL_INFEASIBLE_INACCURATE = 3, TG_MAX_ITER = -2,
+       TG_PRIMAL_INFEASIBLE = -3, TG_UNSOLVED = -10 };
 enum { TG_FAM_6DOF = 0, TG_FAM_XY = 1, TG_FAM_Z = 2, TG_FAM_YAW = 3 };
 enum { TG_MAT_P = 0, TG_MAT_A = 1, TG_MAT_AD = 2, TG_MAT_BD = 3, TG_MAT_Q = 4, TG_MAT_R = 5,
        TG_MAT_KINV = 6, TG_VEC_L = 7, TG_VEC_U = 8, TG_VEC_RHO = 9 };

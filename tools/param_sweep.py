@@ -1,16 +1,20 @@
 """Random model parameters (dt, weights, limits, smoothing) x horizons, both families: the solve
-must launch and agree with the CPU oracle in the engine's mode (development aid; GPU box)."""
+must launch and agree with the CPU oracle in the engine's mode (development aid; GPU box).
+usage: param_sweep.py [seed [trials [long]]]   (default 7 30; "long": horizons to 60 as well)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import trajectory_generation_amd as tg
 from oracle import oracle as O
 O.build()
-rng = np.random.default_rng(7)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+HORIZONS = [3, 5, 10, 16, 20, 27, 35, 50] + ([43, 52, 57, 60] if len(sys.argv) > 3 else [])
+rng = np.random.default_rng(SEED)
 B = 24
 bad = 0
-for trial in range(30):
-    N = int(rng.choice([3, 5, 10, 16, 20, 27, 35, 50]))
+for trial in range(TRIALS):
+    N = int(rng.choice(HORIZONS))
     dt = float(rng.choice([0.05, 0.1, 0.2]))
     smooth = bool(rng.integers(0, 2))
     kw6 = dict(N=N, dt=dt, state_weight=float(10 ** rng.uniform(2, 4.3)), input_weight=float(10 ** rng.uniform(1, 3)),
@@ -30,6 +34,8 @@ for trial in range(30):
         bad += bool(flag)
         print("6dof  trial %2d N %2d dt %.2f smooth %d rho %g info %s solved %d/%d itmax %d mism %d d %.1e%s" % (
             trial, N, dt, smooth, e.rho, e.kernel_info(), ok.sum(), B, ro["iters"].max(), mism, d, flag), flush=True)
+        for i in np.nonzero((r["status"] != ro["status"]) | (r["iters"] != ro["iters"]))[0]:
+            print("      instance %d: engine status %d after %d, oracle status %d after %d" % (i, r["status"][i], r["iters"][i], ro["status"][i], ro["iters"][i]))
     except Exception as ex:
         print("6dof  trial", trial, N, kw6, "FAIL", ex, flush=True); bad += 1
     kw12 = dict(N=N, dt=dt, enable_control_smoothing=smooth,
@@ -54,6 +60,9 @@ for trial in range(30):
         print("12st  trial %2d N %2d dt %.2f smooth %d rho %s info %s solved %d/%d itmax %d mism %d d %.1e%s" % (
             trial, N, dt, smooth, [e.rho(k) for k in ("xy", "z", "yaw")], [e.kernel_info(k)[0] for k in ("z", "xy", "yaw")],
             ok.sum(), B, ro["iters"].max(), mism, d, flag), flush=True)
+        for i, k in zip(*np.nonzero((r["status"] != ro["status"]) | (r["iters"] != ro["iters"]))):
+            print("      instance %d stage %d: engine status %d after %d, oracle status %d after %d" % (
+                i, k, r["status"][i, k], r["iters"][i, k], ro["status"][i, k], ro["iters"][i, k]))
     except Exception as ex:
         print("12st  trial", trial, N, "FAIL", ex, flush=True); bad += 1
 print("problems:", bad)

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("TG_MPC_LIB") or os.path.join(_HERE, "lib", "libtg_mpc
 TG_INFTY = 1e30
 TG_OK, TG_E_ARG, TG_E_HIP, TG_E_STATE, TG_E_NUMERIC = 0, -1, -2, -3, -4
 TG_SOLVED, TG_MAX_ITER, TG_PRIMAL_INFEASIBLE, TG_UNSOLVED = 1, -2, -3, -10
+TG_SOLVED_INACCURATE, TG_PRIMAL_INFEASIBLE_INACCURATE = 2, 3   # OSQP's verdicts of its tenfold-tolerance test at max_iter
 TG_FAM_6DOF, TG_FAM_XY, TG_FAM_Z, TG_FAM_YAW = 0, 1, 2, 3
 (TG_MAT_P, TG_MAT_A, TG_MAT_AD, TG_MAT_BD, TG_MAT_Q, TG_MAT_R, TG_MAT_KINV, TG_VEC_L, TG_VEC_U,
  TG_VEC_RHO) = range(10)

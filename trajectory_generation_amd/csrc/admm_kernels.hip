@@ -1303,9 +1303,21 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             if (!done && (conv || pinf || last)) {
                 done = true;
                 const int inst = slot_inst[t];
+                int verdict = conv ? TG_DEV_SOLVED : (pinf ? TG_DEV_PRIMAL_INFEASIBLE : TG_DEV_MAX_ITER);
+                if (!conv && !pinf) {
+                    // max_iter reached: OSQP tests once more with every tolerance times ten and reports
+                    // "solved inaccurate" / "primal infeasible inaccurate" if that passes (osqp_solve's
+                    // last step; osqp-eigen's solve() returns false for these as for max_iter)
+                    const double ea = P.eps_abs * 10.0, er = P.eps_rel * 10.0, ei = eps_pinf * 10.0;
+                    const bool prim_ok = m_rp < ea + er * fmax(m_ax, m_z);
+                    const bool dual_ok = m_rd < ea + er * fmax(fmax(m_px, m_aty), qn);
+                    if (prim_ok && dual_ok) verdict = TG_DEV_SOLVED_INACCURATE;
+                    else if (!prim_ok && eps_pinf > 0.0 && pin_n > kDivisionTol && pin_l < -ei * pin_n && m_atdy < ei * pin_n)
+                        verdict = TG_DEV_PRIMAL_INFEASIBLE_INACCURATE;
+                }
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
                 // is written for an infeasible instance
-                const bool wr = conv || !pinf;
+                const bool wr = verdict != TG_DEV_PRIMAL_INFEASIBLE && verdict != TG_DEV_PRIMAL_INFEASIBLE_INACCURATE;
 #pragma unroll
                 for (int cc = 0; cc < MAXC; cc++) {
                     const int c = cell_q(cc);
@@ -1321,7 +1333,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                 }
                 if (g == 0) {
-                    if (a.status) a.status[inst] = conv ? TG_DEV_SOLVED : (pinf ? TG_DEV_PRIMAL_INFEASIBLE : TG_DEV_MAX_ITER);
+                    if (a.status) a.status[inst] = verdict;
                     if (a.iters) a.iters[inst] = local;
                     if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.res_ld + inst] = m_rd; }
                 }

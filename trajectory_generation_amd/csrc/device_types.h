@@ -8,6 +8,8 @@ namespace tg {
 constexpr int kTileDev = 16;            // instances per workgroup = MFMA f64 16x16x4 columns
 constexpr double TG_DEV_INFTY = 1e30;   // OsqpEigen::INFTY
 constexpr int TG_DEV_SOLVED = 1, TG_DEV_MAX_ITER = -2, TG_DEV_PRIMAL_INFEASIBLE = -3, TG_DEV_UNSOLVED = -10;
+// OSQP's verdicts of the check with tenfold tolerances that it makes when max_iter is reached
+constexpr int TG_DEV_SOLVED_INACCURATE = 2, TG_DEV_PRIMAL_INFEASIBLE_INACCURATE = 3;
 constexpr double kInfBound = 1e26;      // OSQP_INFTY * MIN_SCALING: bounds beyond it count as infinite
 constexpr double kDivisionTol = 1e-30;  // 1 / OSQP_INFTY
 constexpr int kMaxAxes = 3, kMaxSlots = 4;

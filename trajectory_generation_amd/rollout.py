@@ -35,7 +35,7 @@ def closed_loop(eng, buf, steps, warm=True, record=False, stats_every=0, stream=
             out["iters_max"].append(int(it.max().item()))
             out["solved_frac"].append(float((st == 1).all(0).double().mean().item()))
             out["failed_frac"].append(float((st != 1).any(0).double().mean().item()))
-            out["max_iter_hit_frac"].append(float((st == -2).any(0).double().mean().item()))
+            out["max_iter_hit_frac"].append(float(((st == -2) | (st == 2) | (st == 3)).any(0).double().mean().item()))
         eng.plant_step(buf, stream=stream)
         eng.ref_shift(buf, stream=stream)
         if record:
