@@ -63,6 +63,37 @@ def test_slot_refill_n50_is_bit_identical(tg, oracle, cap):
     assert np.abs(b["X"][idx][oki] - ro["X"][oki]).max() < 1e-9 and np.abs(b["U"][idx][oki] - ro["U"][oki]).max() < 1e-9
 
 
+@pytest.mark.parametrize("N,check,fine", [(20, 25, 5), (50, 25, 5), (20, 10, 5)])
+def test_slot_refill_with_the_finer_check_schedule(tg, oracle, N, check, fine):
+    """check_fine > 0 with refilled slots: a slot whose instance started at a tile iteration that is
+    not a multiple of `check` still gets its infeasibility test (and OSQP's tenfold-tolerance verdict
+    at max_iter) at the multiples of `check` of its own count.  Infeasible instances sit where the
+    queue hands them out late; results equal one workgroup per tile bit for bit and the oracle's."""
+    B = 400
+    p, op = tg.mpc6_params(N=N), oracle.mpc6_params(N=N)
+    x0, ref = oracle.synth_mpc6(SEED + 6, N, 0.1, B)
+    bad = [45, 77, 130, 222, 301, 350, 399]
+    for i in bad:
+        x0[i, 4] = -40.0                             # |v_y(0)| > v_max: infeasible
+    kw = dict(check_termination=check, check_fine=fine, max_iter=40 * check)
+    res = []
+    for gc in (-1, 2):
+        eng = tg.BatchedMPC6(p, tg.make_opts(grid_cap=gc, **kw))
+        res.append(eng.solve_host(x0, ref))
+    a, b = res
+    np.testing.assert_array_equal(a["status"], b["status"])
+    np.testing.assert_array_equal(a["iters"], b["iters"])
+    ok = a["status"] == 1
+    assert np.array_equal(a["X"][ok], b["X"][ok]) and np.array_equal(a["U"][ok], b["U"][ok])
+    assert (a["status"][bad] == -3).all() and ok.sum() == B - len(bad)
+    assert ((a["iters"][ok] - check) % fine == 0).all() and (a["iters"][ok] >= check).all()
+    oracle.match_rho_classes(eng.rho_rows())
+    idx = np.unique(np.concatenate([np.array(bad), np.arange(200, 240)]))
+    ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0, **kw), x0[idx], ref[idx])
+    np.testing.assert_array_equal(b["status"][idx], ro["status"])
+    np.testing.assert_array_equal(b["iters"][idx], ro["iters"])
+
+
 def test_config4_full_size_properties(tg):
     """mpc_6dof, N = 50, one GPU's share of the 262144-instance configuration (32768 instances,
     slots refilled): dynamics roll-out identity, bound satisfaction, every instance solved, and a

@@ -1,0 +1,122 @@
+"""Random model parameters x solver options x inputs, both families, against the CPU oracle in the
+engine's mode: statuses and iteration counts must be equal and solved trajectories agree to 1e-8
+(development aid; GPU box).  Options drawn: eps, alpha, sigma, max_iter, check interval, finer
+checks, infeasibility tolerance, step-size class scales, operator form, grid size (slot refill),
+instance order; inputs: seeded vehicles with a random share in the stress geometry; cold starts.
+usage: fuzz_vs_oracle.py [seed [trials]]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import trajectory_generation_amd as tg
+from trajectory_generation_amd import synth
+from oracle import oracle as O
+O.build()
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+rng = np.random.default_rng(SEED)
+bad = 0
+ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]     # run only these trials (all are drawn)
+
+
+def draw_opts(N):
+    chk = int(rng.choice([5, 10, 25, 25, 25, 50]))
+    fine = int(rng.choice([0, 0, 5])) if chk % 5 == 0 and chk > 5 else 0
+    mi = int(rng.choice([1, 2, 4, 160])) * chk
+    eps = float(rng.choice([1e-2, 1e-3, 1e-3, 1e-4, 1e-5]))
+    o = dict(eps_abs=eps, eps_rel=eps * float(rng.choice([1.0, 1.0, 0.1])), alpha=float(rng.choice([1.0, 1.4, 1.6, 1.6, 1.8])),
+             sigma=float(rng.choice([1e-6, 1e-6, 1e-4])), max_iter=mi, check_termination=chk, check_fine=fine,
+             eps_prim_inf=float(rng.choice([1e-4, 1e-4, 1e-3, 0.0])))
+    e = dict(o)
+    if rng.integers(0, 3) == 0:
+        e["rho_scale"] = tuple(float(v) for v in 10 ** rng.uniform(-0.7, 0.7, 4))
+    e["lowrank"] = int(rng.choice([0, 0, 1, -1]))
+    e["grid_cap"] = int(rng.choice([0, 0, -1, 1, 2, 3]))
+    e["hard_first"] = int(rng.choice([0, -1]))
+    import json
+    e.update(json.loads(os.environ.get("FUZZ_ENGINE_ONLY", "{}")))      # overrides for bisecting a finding
+    for k, v in json.loads(os.environ.get("FUZZ_BOTH", "{}")).items():
+        o[k] = v; e[k] = v
+    return o, e
+
+
+def report(tag, trial, desc, r, ro, solved, tol):
+    global bad
+    mism = int((r["status"] != ro["status"]).sum() + (r["iters"] != ro["iters"]).sum())
+    d = float(np.abs(r["X"][solved] - ro["X"][solved]).max()) if solved.any() else 0.0
+    flag = "" if mism == 0 and d < tol else "  <-- MISMATCH"
+    bad += bool(flag)
+    print("%s trial %3d %s solved %d/%d statuses %s itmax %d mism %d d %.1e%s" % (
+        tag, trial, desc, solved.sum(), len(solved), sorted(set(int(v) for v in np.unique(ro["status"]))), ro["iters"].max(), mism, d, flag), flush=True)
+    if flag:
+        idx = np.argwhere((r["status"] != ro["status"]) | (r["iters"] != ro["iters"]))[:6]
+        for ix in idx:
+            ix = tuple(ix)
+            print("      at %s: engine %d after %d, oracle %d after %d" % (ix, r["status"][ix], r["iters"][ix], ro["status"][ix], ro["iters"][ix]))
+
+
+for trial in range(TRIALS):
+    B = int(rng.integers(1, 100))
+    dt = float(rng.choice([0.05, 0.1, 0.1, 0.2]))
+    smooth = bool(rng.integers(0, 2))
+    share = float(rng.choice([0.0, 0.0, 0.2, 1.0]))
+    # ---------------------------------------------------------------- 6-DOF
+    N = int(rng.integers(1, 82))
+    o, e = draw_opts(N)
+    kw6 = dict(N=N, dt=dt, state_weight=float(10 ** rng.uniform(2, 4.3)), input_weight=float(10 ** rng.uniform(1, 3)),
+               smooth_input_weight=float(10 ** rng.uniform(0, 2)), enable_control_smoothing=smooth,
+               min_altitude=float(rng.uniform(-2, 1)), max_vel=tuple(float(v) for v in rng.uniform(3, 15, 3)),
+               max_accel=tuple(float(v) for v in rng.uniform(2, 10, 3)))
+    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap")})
+    try:
+        if ONLY and trial not in ONLY:
+            raise KeyError("skipped")
+        eng = tg.BatchedMPC6(tg.mpc6_params(**kw6), tg.make_opts(**e))
+        x0, ref = O.synth_mpc6(1000 * SEED + trial, N, dt, B)
+        ns = int(share * B)
+        if ns:
+            x0[:ns], ref[:ns] = synth.stress("6dof", x0[:ns], ref[:ns], N)
+        O.match_rho_classes(eng.rho_rows())
+        op = O.mpc6_params(**kw6)
+        r = eng.solve_host(x0, ref)
+        ro = O.mpc6_batch(op, O.fixed_rho_settings(eng.rho, warm_start=0, **o), x0, ref)
+        report("6dof ", trial, desc, r, ro, ro["status"] == 1, 1e-8)
+    except KeyError:
+        pass
+    except Exception as ex:
+        msg = str(ex)
+        if "horizon too long" in msg and N > 52:
+            print("6dof  trial %3d N %d declined: %s" % (trial, N, msg[:80]), flush=True)
+        else:
+            print("6dof  trial", trial, desc, "FAIL", msg[:200], flush=True); bad += 1
+    # ---------------------------------------------------------------- 12-state chain
+    N = int(rng.integers(1, 61))
+    o, e = draw_opts(N)
+    kw12 = dict(N=N, dt=dt, enable_control_smoothing=smooth,
+                state_weight=tuple(float(10 ** v) for v in rng.uniform(2.5, 4, 3)),
+                input_weight=tuple(float(10 ** v) for v in rng.uniform(1, 2.7, 3)),
+                smooth_input_weight=tuple(float(10 ** v) for v in rng.uniform(1, 2.3, 3)),
+                max_vel=(float(rng.uniform(5, 15)), float(rng.uniform(3, 10)), float(rng.uniform(1, 3))),
+                max_accel=(float(rng.uniform(3, 10)), float(rng.uniform(5, 12)), float(rng.uniform(5, 12))),
+                max_jerk=(float(rng.uniform(10, 40)), float(rng.uniform(10, 50)), float(rng.uniform(5, 20))))
+    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap")})
+    try:
+        if ONLY and trial not in ONLY:
+            raise KeyError("skipped")
+        if ONLY:
+            print("options", o, e, kw12, flush=True)
+        eng = tg.BatchedMPC12(tg.mpc12_params(**kw12), tg.make_opts(**e))
+        x, ref = O.synth_mpc12(2000 * SEED + trial, N, dt, B)
+        ns = int(share * B)
+        if ns:
+            x[:ns], ref[:ns] = synth.stress("12state", x[:ns], ref[:ns], N)
+        r = eng.solve_host(x, ref)
+        O.match_rho_classes(eng.rho_rows())
+        s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
+        ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
+        report("12st ", trial, desc, r, ro, (ro["status"] == 1).all(1), 1e-7)
+    except KeyError:
+        pass
+    except Exception as ex:
+        print("12st  trial", trial, desc, "FAIL", str(ex)[:200], flush=True); bad += 1
+print("problems:", bad)
+sys.exit(1 if bad else 0)

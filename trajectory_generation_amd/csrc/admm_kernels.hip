@@ -1312,7 +1312,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     const bool prim_ok = m_rp < ea + er * fmax(m_ax, m_z);
                     const bool dual_ok = m_rd < ea + er * fmax(fmax(m_px, m_aty), qn);
                     if (prim_ok && dual_ok) verdict = TG_DEV_SOLVED_INACCURATE;
-                    else if (!prim_ok && eps_pinf > 0.0 && pin_n > kDivisionTol && pin_l < -ei * pin_n && m_atdy < ei * pin_n)
+                    else if (sfull && !prim_ok && eps_pinf > 0.0 && pin_n > kDivisionTol && pin_l < -ei * pin_n && m_atdy < ei * pin_n)
                         verdict = TG_DEV_PRIMAL_INFEASIBLE_INACCURATE;
                 }
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
@@ -1417,6 +1417,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (wave == 0) {
                     const unsigned long long mask = __ballot(need && g == 0);
                     int base = 0;
+                    if (lane == 0) next[16] = 0;     // the word the slots' check phases are gathered in below
                     if (lane == 0) base = atomicAdd(a.queue, (int)__popcll(mask));
                     base = __shfl(base, 0);
                     if (need && g == 0) {
@@ -1436,8 +1437,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 if (fresh && (lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
                 if (fresh && g == 0) { slot_inst[t] = ni; slot_start[t] = iter; }
                 if (fine > 0) {
+                    // bitwise OR over the live slots (__syncthreads_or only tells whether any bit is set)
                     const int st0 = fresh ? iter : slot_start[t];
-                    phase_mask = (unsigned)__syncthreads_or(done ? 0 : (int)(1u << ((st0 / fine) % nphase)));
+                    if (g == 0 && !done) atomicOr((unsigned *)&next[16], 1u << ((st0 / fine) % nphase));
+                    __syncthreads();
+                    phase_mask = (unsigned)next[16];
                 } else {
                     __syncthreads();
                 }
