@@ -93,3 +93,19 @@ def test_random_model_parameters_match_the_oracle():
                        stderr=subprocess.STDOUT, timeout=600, cwd=root)
     out = r.stdout.decode()
     assert r.returncode == 0 and "problems: 0" in out, out[-3000:]
+
+
+def test_differential_fuzz_against_the_oracle():
+    """Random model parameters x solver options (tolerances, relaxation, iteration budget, check
+    interval, finer checks, step-size scales, operator form) x grid sizes x inputs with a share in
+    the stress geometry, both families, plus warm-started triples: statuses and iteration counts
+    equal the CPU oracle's, trajectories agree to 1e-8 (tools/fuzz_vs_oracle.py, 25 draws of a fixed
+    seed; the tool takes other seeds for longer runs)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_vs_oracle.py"), "4", "25"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900, cwd=root)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "problems: 0" in out, out[-3000:]

@@ -80,6 +80,26 @@ for trial in range(TRIALS):
         r = eng.solve_host(x0, ref)
         ro = O.mpc6_batch(op, O.fixed_rho_settings(eng.rho, warm_start=0, **o), x0, ref)
         report("6dof ", trial, desc, r, ro, ro["status"] == 1, 1e-8)
+        if rng.integers(0, 3) == 0:
+            # three warm-started solves in a row (the state and the reference move in between), a few
+            # instances one at a time on the oracle's side
+            nb = min(B, 8)
+            eng.reset_warm()
+            seq = [(x0[:nb], ref[:nb])]
+            for k in range(2):
+                seq.append((seq[-1][0] + rng.uniform(-0.05, 0.05, (nb, 6)), seq[-1][1] + rng.uniform(-0.03, 0.03, (nb, 1))))
+            got = [eng.solve_host(a, b, warm=True) for a, b in seq]
+            mism, worst = 0, 0.0
+            for i in range(nb):
+                m = O.Mpc6(op, O.fixed_rho_settings(eng.rho, warm_start=1, **o))
+                for k, (a, b) in enumerate(seq):
+                    res = m.loop(a[i], b[i])
+                    mism += int(res["iters"] != got[k]["iters"][i]) + int(res["status"] != got[k]["status"][i])
+                    if res["status"] == 1:
+                        worst = max(worst, float(np.abs(res["X"] - got[k]["X"][i]).max()))
+            flag = "" if mism == 0 and worst < 1e-8 else "  <-- MISMATCH"
+            bad += bool(flag)
+            print("6dofw trial %3d warm triple on %d instances: mism %d d %.1e%s" % (trial, nb, mism, worst, flag), flush=True)
     except KeyError:
         pass
     except Exception as ex:
