@@ -372,7 +372,10 @@ class Mpc6:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().mpc6_destroy(self._h)
+            try:
+                lib().mpc6_destroy(self._h)
+            except TypeError:        # interpreter shutdown: the module's globals are already gone
+                pass
             self._h = None
 
     def loop(self, x0, ref):
@@ -394,7 +397,10 @@ class Mpc12:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().mpc12_destroy(self._h)
+            try:
+                lib().mpc12_destroy(self._h)
+            except TypeError:
+                pass
             self._h = None
 
     def loop(self, x12, ref12):

@@ -7,6 +7,7 @@ usage: fuzz_vs_oracle.py [seed [trials]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch          # before the engine: both bring a HIP runtime, torch's has to be the one that initialises
 import trajectory_generation_amd as tg
 from trajectory_generation_amd import synth
 from oracle import oracle as O
@@ -80,6 +81,21 @@ for trial in range(TRIALS):
         r = eng.solve_host(x0, ref)
         ro = O.mpc6_batch(op, O.fixed_rho_settings(eng.rho, warm_start=0, **o), x0, ref)
         report("6dof ", trial, desc, r, ro, ro["status"] == 1, 1e-8)
+        if rng.integers(0, 4) == 0 and N <= 40:
+            # QP data of these parameters, bit for bit: P, A, l, u, and q / l / u of a few instances
+            from trajectory_generation_amd import _capi as capi
+            qp = O.build_qp(op)
+            same = all(np.array_equal(eng.get(k), qp[n]) for k, n in ((capi.TG_MAT_P, "P"), (capi.TG_MAT_A, "A"), (capi.TG_VEC_L, "l"), (capi.TG_VEC_U, "u")))
+            nb = min(B, 5)
+            buf = eng.alloc(nb)
+            buf["x0"][:, :nb] = torch.from_numpy(np.ascontiguousarray(x0[:nb].T)).cuda()
+            buf["ref"][:, :nb] = torch.from_numpy(np.ascontiguousarray(ref[:nb].T)).cuda()
+            q, l, u = [t.cpu().numpy() for t in eng.assemble(buf)]
+            for b in range(nb):
+                qo, lo, uo = O.qp6_vectors(op, x0[b], ref[b])
+                same = same and np.array_equal(q[:, b], qo) and np.array_equal(l[:, b], lo) and np.array_equal(u[:, b], uo)
+            bad += not same
+            print("6dofq trial %3d QP data bit for bit: %s%s" % (trial, same, "" if same else "  <-- MISMATCH"), flush=True)
         if rng.integers(0, 3) == 0:
             # three warm-started solves in a row (the state and the reference move in between), a few
             # instances one at a time on the oracle's side
@@ -134,6 +150,32 @@ for trial in range(TRIALS):
         s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
         ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
         report("12st ", trial, desc, r, ro, (ro["status"] == 1).all(1), 1e-7)
+        if rng.integers(0, 4) == 0 and N <= 30:
+            from trajectory_generation_amd import _capi as capi
+            op12 = O.mpc12_params(**kw12)
+            same = True
+            for stage, fam in (("xy", O.FAM_XY), ("z", O.FAM_Z), ("yaw", O.FAM_YAW)):
+                qp = O.build_qp(op12, fam)
+                same = same and all(np.array_equal(eng.get(stage, k), qp[n]) for k, n in ((capi.TG_MAT_P, "P"), (capi.TG_MAT_A, "A"), (capi.TG_VEC_L, "l"), (capi.TG_VEC_U, "u")))
+            bad += not same
+            print("12stq trial %3d stage matrices bit for bit: %s%s" % (trial, same, "" if same else "  <-- MISMATCH"), flush=True)
+        if rng.integers(0, 4) == 0:
+            # the chain warm-started (an option the reference does not use): two solves in a row
+            nb = min(B, 5)
+            eng.reset_warm()
+            x1 = x[:nb] + rng.uniform(-0.03, 0.03, (nb, 12)); r1 = ref[:nb] + rng.uniform(-0.02, 0.02, (nb, 1))
+            got = [eng.solve_host(x[:nb], ref[:nb], warm=True), eng.solve_host(x1, r1, warm=True)]
+            mism, worst = 0, 0.0
+            for i in range(nb):
+                m = O.Mpc12(O.mpc12_params(**kw12), {k: O.fixed_rho_settings(eng.rho(k), warm_start=1, **o) for k in ("xy", "z", "yaw")})
+                for k, (a, b) in enumerate(((x[:nb], ref[:nb]), (x1, r1))):
+                    res = m.loop(a[i], b[i])
+                    mism += int((res["iters"] != got[k]["iters"][i]).sum()) + int((res["status"] != got[k]["status"][i]).sum())
+                    if (res["status"] == 1).all():
+                        worst = max(worst, float(np.abs(res["X"] - got[k]["X"][i]).max()))
+            flag = "" if mism == 0 and worst < 1e-7 else "  <-- MISMATCH"
+            bad += bool(flag)
+            print("12stw trial %3d warm pair on %d instances: mism %d d %.1e%s" % (trial, nb, mism, worst, flag), flush=True)
     except KeyError:
         pass
     except Exception as ex:

@@ -138,7 +138,7 @@ struct DevStage {
                 // (the streamed low-rank 6-DOF variant is compiled for five cells per thread: N <= 52;
                 // longer horizons take the dense variant with eight)
                 const bool lr_compiled = !six || cells <= 5;
-                dev.lr = (sp.lr_q > 0 && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && lr_compiled && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
+                dev.lr = (sp.lr_q > 0 && lr_compiled && (lowrank_mode > 0 || (lowrank_mode == 0 && !in_registers && 5 * lr_mfma <= 3 * dense_mfma))) ? 1 : 0;
                 dev.lr_q = sp.lr_q; dev.lr_crb = sp.lr_crb; dev.lr_uk = sp.lr_uk; dev.sb_rows = sp.lr_crb * 16 + 8;
                 // streamed low-rank form: C r as two partial sums (the k range of a row block of C is
                 // cut in two items, so that the first stage spreads evenly over the waves)
