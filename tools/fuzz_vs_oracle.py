@@ -76,6 +76,10 @@ for trial in range(TRIALS):
         ns = int(share * B)
         if ns:
             x0[:ns], ref[:ns] = synth.stress("6dof", x0[:ns], ref[:ns], N)
+        if rng.integers(0, 4) == 0:            # a few vehicles report a speed outside the limits: infeasible QPs
+            for i in rng.choice(B, size=min(B, 3), replace=False):
+                ax = int(rng.integers(0, 3))
+                x0[i, 3 + ax] = float(rng.choice([-1, 1])) * kw6["max_vel"][ax] * float(rng.uniform(1.05, 3.0))
         O.match_rho_classes(eng.rho_rows())
         op = O.mpc6_params(**kw6)
         r = eng.solve_host(x0, ref)
@@ -145,6 +149,10 @@ for trial in range(TRIALS):
         ns = int(share * B)
         if ns:
             x[:ns], ref[:ns] = synth.stress("12state", x[:ns], ref[:ns], N)
+        if rng.integers(0, 4) == 0:            # speeds outside the limits in one of the three stages
+            for i in rng.choice(B, size=min(B, 3), replace=False):
+                col, lim = [(1, kw12["max_vel"][0]), (4, kw12["max_vel"][0]), (7, kw12["max_vel"][1]), (10, kw12["max_vel"][2])][int(rng.integers(0, 4))]
+                x[i, col] = float(rng.choice([-1, 1])) * lim * float(rng.uniform(1.05, 3.0))
         r = eng.solve_host(x, ref)
         O.match_rho_classes(eng.rho_rows())
         s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
