@@ -134,6 +134,10 @@ void tg_mpc6_destroy(tg_mpc6 *h);
  *   X   [6(N+1)][ld]     getOptimalStateTraj   :805
  *   U   [3N][ld]         getOptimalControlTraj :811
  *   status[B], iters[B]  (may be NULL)
+ * X and U of an instance are written only when its status is TG_SOLVED: mpcLoop returns
+ * before extractSolution when solve() is false (mpc_6dof.cpp:639-647), so the columns of a
+ * failed instance keep what they held (the plan of its last successful solve, if the
+ * caller reuses the arrays; the host variants below zero them first).
  * warm != 0 continues from the iterates the handle keeps for slots [0,B) (the
  * reference's setWarmStart(true), mpc_6dof.cpp:528) and stores the new ones; the
  * first warm call of a handle starts cold.  stream: hipStream_t or NULL. */

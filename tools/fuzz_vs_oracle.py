@@ -120,6 +120,48 @@ for trial in range(TRIALS):
             flag = "" if mism == 0 and worst < 1e-8 else "  <-- MISMATCH"
             bad += bool(flag)
             print("6dofw trial %3d warm triple on %d instances: mism %d d %.1e%s" % (trial, nb, mism, worst, flag), flush=True)
+        if rng.integers(0, 5) == 0 and N <= 30 and N >= 2:
+            # closed loop, warm-started: solve, gated plant step, reference shift, for a few vehicles
+            # and steps; one vehicle reports a speed outside its limits at one step (a failed solve:
+            # it keeps following the plan it last received).  The same loop on the host with the oracle.
+            from trajectory_generation_amd import _capi as capi
+            nb, steps = min(B, 5), 7
+            A, Bm = eng.get(capi.TG_MAT_AD), eng.get(capi.TG_MAT_BD)
+            xs, rs = O.synth_mpc6(3000 * SEED + trial, N, dt, nb)
+            fault = (int(rng.integers(1, steps)), int(rng.integers(0, nb)), 3 + int(rng.integers(0, 3)))
+            eng.reset_warm()
+            buf = eng.alloc(nb)
+            buf["x0"][:, :nb] = torch.from_numpy(np.ascontiguousarray(xs.T)).cuda()
+            buf["ref"][:, :nb] = torch.from_numpy(np.ascontiguousarray(rs.T)).cuda()
+            hist, stat = [], []
+            for k in range(steps):
+                if k == fault[0]:
+                    buf["x0"][fault[2], fault[1]] = 4.0 * kw6["max_vel"][fault[2] - 3]
+                eng.solve(buf, warm=True)
+                stat.append(buf["status"][:nb].cpu().numpy().copy())
+                eng.plant_step(buf); eng.ref_shift(buf)
+                hist.append(buf["x0"][:, :nb].T.cpu().numpy().copy())
+            worst, mism = 0.0, 0
+            for b in range(nb):
+                m = O.Mpc6(op, O.fixed_rho_settings(eng.rho, warm_start=1, **o))
+                x, r, plan = xs[b].copy(), rs[b].copy(), np.zeros(3 * N)
+                for k in range(steps):
+                    if k == fault[0] and b == fault[1]:
+                        x[fault[2]] = 4.0 * kw6["max_vel"][fault[2] - 3]
+                    res = m.loop(x, r)
+                    mism += int(res["status"] != stat[k][b])
+                    if res["status"] == 1:
+                        plan = res["U"].copy()
+                    else:
+                        plan = np.concatenate([plan[3:], np.zeros(3)])
+                    x = A @ x + Bm @ plan[:3]
+                    rr = r.reshape(N + 1, 6).copy(); last = rr[N] + (rr[N] - rr[N - 1]); rr[:-1] = rr[1:]; rr[N] = last
+                    r = rr.ravel()
+                    worst = max(worst, float(np.abs(hist[k][b] - x).max()))
+            flag = "" if mism == 0 and worst < 1e-6 else "  <-- MISMATCH"
+            bad += bool(flag)
+            print("6dofc trial %3d closed loop %d vehicles x %d steps, fault %s: status mism %d, state d %.1e%s" % (
+                trial, nb, steps, fault, mism, worst, flag), flush=True)
     except KeyError:
         pass
     except Exception as ex:

@@ -1315,9 +1315,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     else if (sfull && !prim_ok && eps_pinf > 0.0 && pin_n > kDivisionTol && pin_l < -ei * pin_n && m_atdy < ei * pin_n)
                         verdict = TG_DEV_PRIMAL_INFEASIBLE_INACCURATE;
                 }
-                // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551); nothing
-                // is written for an infeasible instance
-                const bool wr = verdict != TG_DEV_PRIMAL_INFEASIBLE && verdict != TG_DEV_PRIMAL_INFEASIBLE_INACCURATE;
+                // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551): for solved
+                // instances only -- mpcLoop returns before extractSolution when solve() is false, so a
+                // failed instance keeps the trajectories of its last successful solve
+                const bool wr = verdict == TG_DEV_SOLVED;
 #pragma unroll
                 for (int cc = 0; cc < MAXC; cc++) {
                     const int c = cell_q(cc);
