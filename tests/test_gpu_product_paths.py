@@ -94,6 +94,44 @@ def test_slot_refill_with_the_finer_check_schedule(tg, oracle, N, check, fine):
     np.testing.assert_array_equal(b["iters"][idx], ro["iters"])
 
 
+def test_failed_instances_keep_their_columns(tg, oracle):
+    """X and U are written for solved instances only: mpcLoop returns before extractSolution when
+    solve() is false (mpc_6dof.cpp:639-647), whatever the reason -- max_iter, OSQP's inaccurate
+    verdicts, infeasibility."""
+    import torch
+    N, B = 20, 96
+    eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(eps_abs=1e-4, eps_rel=1e-4, max_iter=25))
+    x0, ref = oracle.synth_mpc6(SEED + 21, N, 0.1, B)
+    x0[5, 4] = -40.0                                  # infeasible
+    buf = eng.alloc(B)
+    _to_dev(buf, x0, ref)
+    buf["X"].fill_(-3.0); buf["U"].fill_(-3.0)
+    eng.solve(buf)
+    torch.cuda.synchronize()
+    st = buf["status"][:B].cpu().numpy()
+    X = buf["X"][:, :B].cpu().numpy(); U = buf["U"][:, :B].cpu().numpy()
+    assert 2 in st and st[5] in (3, -3) and (st != 1).sum() > 10      # solved inaccurate at max_iter, and the infeasible one
+    failed = st != 1
+    assert (X[:, failed] == -3.0).all() and (U[:, failed] == -3.0).all()
+    assert not (X[:, ~failed] == -3.0).any() if (~failed).any() else True
+
+
+def test_forced_lowrank_falls_back_where_no_variant_is_compiled(tg, oracle):
+    """lowrank = 1 asks for the low-rank operators wherever possible: at N = 60 no 6-DOF low-rank
+    variant is compiled (five cells per thread reach to N = 52) and the dense form is taken instead
+    of an error."""
+    N, B = 60, 20
+    x0, ref = oracle.synth_mpc6(SEED + 5, N, 0.1, B)
+    a = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(lowrank=1))
+    b = tg.BatchedMPC6(tg.mpc6_params(N=N))
+    assert not a.kernel_info()[1] and not b.kernel_info()[1]
+    ra, rb = a.solve_host(x0, ref), b.solve_host(x0, ref)
+    np.testing.assert_array_equal(ra["status"], rb["status"])
+    np.testing.assert_array_equal(ra["iters"], rb["iters"])
+    assert np.array_equal(ra["X"], rb["X"]) and (ra["status"] == 1).all()
+    assert tg.BatchedMPC6(tg.mpc6_params(N=52), tg.make_opts(lowrank=1)).kernel_info()[1]
+
+
 def test_config4_full_size_properties(tg):
     """mpc_6dof, N = 50, one GPU's share of the 262144-instance configuration (32768 instances,
     slots refilled): dynamics roll-out identity, bound satisfaction, every instance solved, and a
