@@ -16,6 +16,7 @@ SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rng = np.random.default_rng(SEED)
 bad = 0
+WILD = bool(os.environ.get("FUZZ_WILD"))      # parameters far outside the usual ranges
 ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]     # run only these trials (all are drawn)
 
 
@@ -43,7 +44,7 @@ def draw_opts(N):
 def report(tag, trial, desc, r, ro, solved, tol):
     global bad
     mism = int((r["status"] != ro["status"]).sum() + (r["iters"] != ro["iters"]).sum())
-    d = float(np.abs(r["X"][solved] - ro["X"][solved]).max()) if solved.any() else 0.0
+    d = float(np.abs(r["X"][solved] - ro["X"][solved]).max() / max(1.0, np.abs(ro["X"][solved]).max())) if solved.any() else 0.0   # relative to the largest entry
     flag = "" if mism == 0 and d < tol else "  <-- MISMATCH"
     bad += bool(flag)
     print("%s trial %3d %s solved %d/%d statuses %s itmax %d mism %d d %.1e%s" % (
@@ -72,6 +73,12 @@ for trial in range(TRIALS):
                smooth_input_weight=float(10 ** rng.uniform(0, 2)), enable_control_smoothing=smooth,
                min_altitude=float(rng.uniform(-2, 1)), max_vel=tuple(float(v) for v in rng.uniform(3, 15, 3)),
                max_accel=tuple(float(v) for v in rng.uniform(2, 10, 3)))
+    if WILD:        # far outside what a vehicle would be configured with
+        dt = float(rng.choice([0.01, 0.02, 0.5, 1.0])); kw6["dt"] = dt
+        kw6.update(state_weight=float(10 ** rng.uniform(-1, 6)), input_weight=float(10 ** rng.uniform(-2, 5)),
+                   smooth_input_weight=float(10 ** rng.uniform(-2, 4)), min_altitude=float(rng.uniform(-50, 4)),
+                   max_vel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2.5, 3)),
+                   max_accel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2.5, 3)))
     desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap")})
     try:
         if ONLY and trial not in ONLY:
@@ -187,6 +194,13 @@ for trial in range(TRIALS):
                 max_vel=(float(rng.uniform(5, 15)), float(rng.uniform(3, 10)), float(rng.uniform(1, 3))),
                 max_accel=(float(rng.uniform(3, 10)), float(rng.uniform(5, 12)), float(rng.uniform(5, 12))),
                 max_jerk=(float(rng.uniform(10, 40)), float(rng.uniform(10, 50)), float(rng.uniform(5, 20))))
+    if WILD:
+        kw12.update(dt=dt, state_weight=tuple(float(10 ** v) for v in rng.uniform(-1, 6, 3)),
+                    input_weight=tuple(float(10 ** v) for v in rng.uniform(-2, 5, 3)),
+                    smooth_input_weight=tuple(float(10 ** v) for v in rng.uniform(-2, 4, 3)),
+                    max_vel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2, 3)),
+                    max_accel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2, 3)),
+                    max_jerk=tuple(float(v) for v in 10 ** rng.uniform(0, 3, 3)))
     desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap")})
     try:
         if ONLY and trial not in ONLY:
@@ -229,7 +243,7 @@ for trial in range(TRIALS):
                     res = m.loop(a[i], b[i])
                     mism += int((res["iters"] != got[k]["iters"][i]).sum()) + int((res["status"] != got[k]["status"][i]).sum())
                     if (res["status"] == 1).all():
-                        worst = max(worst, float(np.abs(res["X"] - got[k]["X"][i]).max()))
+                        worst = max(worst, float(np.abs(res["X"] - got[k]["X"][i]).max() / max(1.0, np.abs(res["X"]).max())))
             flag = "" if mism == 0 and worst < 1e-7 else "  <-- MISMATCH"
             bad += bool(flag)
             print("12stw trial %3d warm pair on %d instances: mism %d d %.1e%s" % (trial, nb, mism, worst, flag), flush=True)
