@@ -17,7 +17,13 @@ TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rng = np.random.default_rng(SEED)
 bad = 0
 WILD = bool(os.environ.get("FUZZ_WILD"))      # parameters far outside the usual ranges
+PROGRESS = bool(os.environ.get("FUZZ_PROGRESS"))   # a line before every engine / oracle call: a stall names its place
 ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]     # run only these trials (all are drawn)
+
+
+def mark(msg):
+    if PROGRESS:
+        print("   ... " + msg, flush=True)
 
 
 def draw_opts(N):
@@ -69,6 +75,7 @@ for trial in range(TRIALS):
     o, e = draw_opts(N)
     if big:
         e["grid_cap"] = 0
+        o["max_iter"] = e["max_iter"] = min(o["max_iter"], 400)    # the oracle runs these thousands of instances on one core
     kw6 = dict(N=N, dt=dt, state_weight=float(10 ** rng.uniform(2, 4.3)), input_weight=float(10 ** rng.uniform(1, 3)),
                smooth_input_weight=float(10 ** rng.uniform(0, 2)), enable_control_smoothing=smooth,
                min_altitude=float(rng.uniform(-2, 1)), max_vel=tuple(float(v) for v in rng.uniform(3, 15, 3)),
@@ -94,7 +101,9 @@ for trial in range(TRIALS):
                 x0[i, 3 + ax] = float(rng.choice([-1, 1])) * kw6["max_vel"][ax] * float(rng.uniform(1.05, 3.0))
         O.match_rho_classes(eng.rho_rows())
         op = O.mpc6_params(**kw6)
+        mark("6dof  trial %3d %s: engine" % (trial, desc))
         r = eng.solve_host(x0, ref)
+        mark("6dof  trial %3d engine done (iters max %d), oracle" % (trial, r["iters"].max()))
         ro = O.mpc6_batch(op, O.fixed_rho_settings(eng.rho, warm_start=0, **o), x0, ref)
         report("6dof ", trial, desc, r, ro, ro["status"] == 1, 1e-8)
         if rng.integers(0, 4) == 0 and N <= 40:
@@ -120,7 +129,9 @@ for trial in range(TRIALS):
             seq = [(x0[:nb], ref[:nb])]
             for k in range(2):
                 seq.append((seq[-1][0] + rng.uniform(-0.05, 0.05, (nb, 6)), seq[-1][1] + rng.uniform(-0.03, 0.03, (nb, 1))))
+            mark("6dofw trial %3d: engine" % trial)
             got = [eng.solve_host(a, b, warm=True) for a, b in seq]
+            mark("6dofw trial %3d engine done, oracle" % trial)
             mism, worst = 0, 0.0
             for i in range(nb):
                 m = O.Mpc6(op, O.fixed_rho_settings(eng.rho, warm_start=1, **o))
@@ -187,6 +198,7 @@ for trial in range(TRIALS):
     o, e = draw_opts(N)
     if big:
         e["grid_cap"] = 0
+        o["max_iter"] = e["max_iter"] = min(o["max_iter"], 400)    # the oracle runs these thousands of instances on one core
     kw12 = dict(N=N, dt=dt, enable_control_smoothing=smooth,
                 state_weight=tuple(float(10 ** v) for v in rng.uniform(2.5, 4, 3)),
                 input_weight=tuple(float(10 ** v) for v in rng.uniform(1, 2.7, 3)),
@@ -216,7 +228,9 @@ for trial in range(TRIALS):
             for i in rng.choice(B, size=min(B, 3), replace=False):
                 col, lim = [(1, kw12["max_vel"][0]), (4, kw12["max_vel"][0]), (7, kw12["max_vel"][1]), (10, kw12["max_vel"][2])][int(rng.integers(0, 4))]
                 x[i, col] = float(rng.choice([-1, 1])) * lim * float(rng.uniform(1.05, 3.0))
+        mark("12st  trial %3d %s: engine" % (trial, desc))
         r = eng.solve_host(x, ref)
+        mark("12st  trial %3d engine done (iters max %d), oracle" % (trial, r["iters"].max()))
         O.match_rho_classes(eng.rho_rows())
         s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
         ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
@@ -235,7 +249,9 @@ for trial in range(TRIALS):
             nb = min(B, 5)
             eng.reset_warm()
             x1 = x[:nb] + rng.uniform(-0.03, 0.03, (nb, 12)); r1 = ref[:nb] + rng.uniform(-0.02, 0.02, (nb, 1))
+            mark("12stw trial %3d: engine" % trial)
             got = [eng.solve_host(x[:nb], ref[:nb], warm=True), eng.solve_host(x1, r1, warm=True)]
+            mark("12stw trial %3d engine done, oracle" % trial)
             mism, worst = 0, 0.0
             for i in range(nb):
                 m = O.Mpc12(O.mpc12_params(**kw12), {k: O.fixed_rho_settings(eng.rho(k), warm_start=1, **o) for k in ("xy", "z", "yaw")})
