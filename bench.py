@@ -46,6 +46,7 @@ PIPELINE = {"mpc_12state_B4096_N20": 6, "mpc_6dof_B4096_N20": 4, "mpc_6dof_B3276
             "rollout_12state_B8192_N20": 4}   # closed loop: sub-fleets, each on its own stream   # default batches in flight (--pipeline 0)
 MIN_TIMED_S = 0.5              # shorter regions are repeated until this much has been timed
 PROFILE_ROUND = "r02"
+TIGHT_EPS, TIGHT_SAMPLE = 1e-9, 64   # parity figures: both sides run to convergence on this many instances
 
 
 def dense_flops_per_iteration(model, N):
@@ -116,9 +117,9 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=0,
     if stress:
         x0, ref = synth_stress(model, x0, ref, N)
 
-    def parallel(s):
+    def parallel(s, count=None):
         """one contiguous chunk of instances per thread (ctypes releases the GIL inside the solver)"""
-        edges = np.linspace(0, sample, threads + 1).astype(int)
+        edges = np.linspace(0, sample if count is None else count, threads + 1).astype(int)
         t = time.perf_counter()
         with ThreadPoolExecutor(threads) as ex:
             parts = list(ex.map(lambda k: run(s, edges[k], edges[k + 1]), range(threads)))
@@ -137,6 +138,10 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=0,
     s_eng = fixed(rho) if model == "6dof" else {k: fixed(rho[i]) for i, k in enumerate(("xy", "z", "yaw"))}
     t = time.perf_counter(); re = run(s_eng, 0, single); dte = time.perf_counter() - t
     O.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    # the same OSQP-default path run to a tight tolerance on the first TIGHT_SAMPLE instances: what its
+    # solutions converge to (for the parity figures; not timed)
+    rt, _ = parallel(O.default_settings(warm_start=0, eps_abs=TIGHT_EPS, eps_rel=TIGHT_EPS, max_iter=100000, linsys=1),
+                     min(TIGHT_SAMPLE, sample))
     solved = lambda r: float((r["status"].reshape(len(r["status"]), -1) == 1).all(1).mean())
     base = {"value": sample / dtall, "unit": "solves/s", "cores": threads, "kind": "port",
             "sample": "first %d instances of the same seeded workload, cold-started, one instance per thread on %d "
@@ -150,7 +155,8 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=0,
                             "solved_frac": solved(r1)},
             "same_algorithm_as_gpu_single_core": {"value": single / dte, "instances": single,
                                                   "iters_mean": float(np.mean(re["iters"])), "solved_frac": solved(re)}}
-    return base, dict(x0=x0, ref=ref, X=rall["X"], U=rall["U"], status=rall["status"].reshape(sample, -1))
+    return base, dict(x0=x0, ref=ref, X=rall["X"], U=rall["U"], status=rall["status"].reshape(sample, -1),
+                      tight=dict(X=rt["X"], U=rt["U"], status=rt["status"].reshape(len(rt["X"]), -1)))
 
 
 def self_launch(args, argv):
@@ -535,9 +541,18 @@ def parity_figures(tg, eng, model, N, args, smp):
     ok = ((r["status"].reshape(S, -1) == 1).all(1) & (t["status"].reshape(S, -1) == 1).all(1) &
           (smp["status"] == 1).all(1))
     d = lambda a, b: float(max(np.abs(a["X"][ok] - b["X"][ok]).max(), np.abs(a["U"][ok] - b["U"][ok]).max())) if ok.any() else None
+    # both sides run to convergence (the engine at eps 1e-9, the OSQP-default path at TIGHT_EPS): the
+    # sense in which "within 1e-4 of the reference's solutions" is well defined on these problems
+    tt = smp["tight"]
+    T = tt["X"].shape[0]
+    okt = (t["status"].reshape(S, -1)[:T] == 1).all(1) & (tt["status"] == 1).all(1)
+    conv = float(max(np.abs(t["X"][:T][okt] - tt["X"][okt]).max(), np.abs(t["U"][:T][okt] - tt["U"][okt]).max())) if okt.any() else None
     return {"instances": int(S), "solved_by_both": int(ok.sum()), "eps": args.eps,
             "gpu_vs_osqp_defaults_maxabs": d(r, smp), "gpu_vs_optimum_maxabs": d(r, t),
             "osqp_defaults_vs_optimum_maxabs": d(smp, t),
+            "converged_gpu_vs_converged_osqp_defaults_maxabs": conv,
+            "converged": {"instances": int(T), "solved_by_both": int(okt.sum()), "gpu_eps": 1e-9, "osqp_defaults_eps": TIGHT_EPS,
+                          "target": 1e-4},
             "note": "osqp_defaults = the published OSQP algorithm restated (upstream OSQP is not available offline: "
                     "parity unpinned); optimum = this engine at eps 1e-9"}
 

@@ -206,6 +206,33 @@ def test_parity_figure_config2_vs_osqp_defaults(tg, oracle):
     assert max(g_o) <= max(g_t) + max(o_t) + 1e-12
 
 
+def test_converged_engine_matches_converged_osqp_defaults(tg, oracle):
+    """Both paths run to convergence (eps_abs = eps_rel = 1e-9): the engine and the restated
+    OSQP-default path (Ruiz scaling, adaptive rho, sparse LDL') agree within 1e-4 on X and U, the
+    tolerance the headline target names -- 6-DOF at N = 50 and N = 20, the 12-state chain at N = 20."""
+    tight = tg.make_opts(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+    oracle.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    osqp = oracle.default_settings(warm_start=0, eps_abs=1e-9, eps_rel=1e-9, max_iter=100000, linsys=1)
+    for N, B, off in ((50, 12, 4), (20, 32, 2)):
+        x0, ref = oracle.synth_mpc6(SEED + off, N, 0.1, B)
+        r = tg.BatchedMPC6(tg.mpc6_params(N=N), tight).solve_host(x0, ref)
+        ro = oracle.mpc6_batch(oracle.mpc6_params(N=N), osqp, x0, ref)
+        ok = (r["status"] == 1) & (ro["status"] == 1)
+        assert ok.sum() >= B - 1
+        d = max(_maxabs(r, ro, ok))
+        print("6-DOF N = %d converged on both sides: max-abs %.2e over %d instances" % (N, d, ok.sum()))
+        assert d < 1e-4
+    N, B = 20, 24
+    x, ref = oracle.synth_mpc12(SEED + 3, N, 0.1, B)
+    r = tg.BatchedMPC12(tg.mpc12_params(N=N), tight).solve_host(x, ref)
+    ro = oracle.mpc12_batch(oracle.mpc12_params(N=N), osqp, x, ref)
+    ok = (r["status"] == 1).all(1) & (ro["status"] == 1).all(1)
+    assert ok.sum() >= B // 3
+    d = max(_maxabs(r, ro, ok))
+    print("12-state N = %d converged on both sides: max-abs %.2e over %d instances" % (N, d, ok.sum()))
+    assert d < 1e-4
+
+
 def test_parity_figure_config3_vs_osqp_defaults(tg, oracle):
     """12-state, N = 20, 256 instances, the three chained QPs at eps 1e-3, instances every side
     solves in all three stages.  Positions agree to 0.2 m, the whole trajectories (velocities,
