@@ -67,7 +67,8 @@ typedef struct {
 /* Solver options.  The reference leaves every OSQP setting at its default except
  * warm start (mpc_6dof.cpp:527-528, mpc_12state.cpp:1024-1065); the engine runs the
  * same ADMM with OSQP's scaling and rho adaptation switched off and a fixed rho.
- * rho <= 0 selects the built-in per-family choice. */
+ * rho <= 0 selects the built-in per-family choice (fixed at create; for the 6-DOF model with
+ * N > 30 it is four times larger when the handle is created with eps_abs, eps_rel <= 1e-6). */
 typedef struct {
     double rho;               /* <=0: automatic */
     double sigma;             /* 1e-6 */

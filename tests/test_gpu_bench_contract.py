@@ -47,6 +47,9 @@ def test_bench_line_single_rank():
     # (max over 2048 trajectories of 456 entries each, N = 50: the far end of the horizon is loosely determined)
     assert par["gpu_vs_optimum_maxabs"] < 2.5 and par["gpu_vs_optimum_maxabs"] <= par["osqp_defaults_vs_optimum_maxabs"]
     assert par["gpu_vs_osqp_defaults_maxabs"] <= par["gpu_vs_optimum_maxabs"] + par["osqp_defaults_vs_optimum_maxabs"] + 1e-12
+    # both sides run to convergence: within the target's 1e-4
+    assert par["converged"]["solved_by_both"] >= 0.9 * par["converged"]["instances"] >= 28
+    assert par["converged_gpu_vs_converged_osqp_defaults_maxabs"] < par["converged"]["target"] == 1e-4
 
 
 def test_bench_self_launches_its_ranks():

@@ -233,6 +233,33 @@ def test_converged_engine_matches_converged_osqp_defaults(tg, oracle):
     assert d < 1e-4
 
 
+def test_automatic_step_size_follows_the_tolerance_at_long_horizons(tg, oracle):
+    """A 6-DOF handle with N > 30 created with eps <= 1e-6 takes four times the automatic step size
+    (fewer iterations to a tight tolerance); at the default tolerance, at short horizons and with
+    an explicit rho nothing changes.  The tight handle still agrees with the oracle run with the
+    step size it reports."""
+    tight = dict(eps_abs=1e-7, eps_rel=1e-7, max_iter=100000)
+    base = tg.BatchedMPC6(tg.mpc6_params(N=50)).rho
+    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(**tight)).rho == 4.0 * base
+    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(eps_abs=1e-7, eps_rel=1e-3)).rho == base
+    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(rho=base, **tight)).rho == base
+    assert tg.BatchedMPC6(tg.mpc6_params(N=20), tg.make_opts(**tight)).rho == tg.BatchedMPC6(tg.mpc6_params(N=20)).rho
+    N, B = 50, 24
+    x0, ref = oracle.synth_mpc6(SEED + 9, N, 0.1, B)
+    eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(**tight))
+    slow = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(rho=base, **tight))
+    r, rs = eng.solve_host(x0, ref), slow.solve_host(x0, ref)
+    oracle.match_rho_classes(eng.rho_rows())
+    ro = oracle.mpc6_batch(oracle.mpc6_params(N=N), oracle.fixed_rho_settings(eng.rho, warm_start=0, **tight), x0, ref)
+    assert (r["status"] == 1).all() and np.array_equal(r["status"], ro["status"]) and np.array_equal(r["iters"], ro["iters"])
+    assert max(_maxabs(r, ro, ro["status"] == 1)) < 1e-9
+    # two iterates that both pass at eps 1e-7 sit within a few 1e-3 of the optimum on these problems
+    assert (rs["status"] == 1).all() and max(_maxabs(r, rs, rs["status"] == 1)) < 1e-2
+    assert r["iters"].mean() < rs["iters"].mean()
+    print("N = 50, eps 1e-7: iterations mean %.0f max %d with the automatic step size, %.0f / %d with that of the default tolerance"
+          % (r["iters"].mean(), r["iters"].max(), rs["iters"].mean(), rs["iters"].max()))
+
+
 def test_parity_figure_config3_vs_osqp_defaults(tg, oracle):
     """12-state, N = 20, 256 instances, the three chained QPs at eps 1e-3, instances every side
     solves in all three stages.  Positions agree to 0.2 m, the whole trajectories (velocities,
