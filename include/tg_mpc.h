@@ -67,8 +67,7 @@ typedef struct {
 /* Solver options.  The reference leaves every OSQP setting at its default except
  * warm start (mpc_6dof.cpp:527-528, mpc_12state.cpp:1024-1065); the engine runs the
  * same ADMM with OSQP's scaling and rho adaptation switched off and a fixed rho.
- * rho <= 0 selects the built-in per-family choice (fixed at create; for the 6-DOF model with
- * N > 30 it is four times larger when the handle is created with eps_abs, eps_rel <= 1e-6). */
+ * rho <= 0 selects the built-in per-family choice. */
 typedef struct {
     double rho;               /* <=0: automatic */
     double sigma;             /* 1e-6 */
@@ -79,7 +78,9 @@ typedef struct {
     /* multipliers of rho on the box rows of positions, velocities, accelerations (12-state)
      * and inputs; the XY mixed rows use the velocity / acceleration entries.  OSQP has one rho
      * for all inequality rows and adapts it at run time; a fixed rho per class of row takes
-     * the place of that adaptation.  0 = the built-in choice, 1 = OSQP's uniform rho. */
+     * the place of that adaptation.  0 = the built-in choice, 1 = OSQP's uniform rho.  The
+     * built-in choice is fixed at create and follows the tolerances given there: a 6-DOF handle
+     * with N > 30 created with eps_abs, eps_rel <= 1e-5 takes scales suited to tight runs. */
     double rho_scale[4];
     /* OSQP's eps_prim_inf (1e-4): tolerance of the primal infeasibility certificate tested at
      * every termination check; 0 switches the test off.  Dual infeasibility cannot occur: the

@@ -233,21 +233,24 @@ def test_converged_engine_matches_converged_osqp_defaults(tg, oracle):
     assert d < 1e-4
 
 
-def test_automatic_step_size_follows_the_tolerance_at_long_horizons(tg, oracle):
-    """A 6-DOF handle with N > 30 created with eps <= 1e-6 takes four times the automatic step size
-    (fewer iterations to a tight tolerance); at the default tolerance, at short horizons and with
-    an explicit rho nothing changes.  The tight handle still agrees with the oracle run with the
-    step size it reports."""
+def test_automatic_step_sizes_follow_the_tolerance_at_long_horizons(tg, oracle):
+    """A 6-DOF handle with N > 30 created with eps <= 1e-5 takes per-class step sizes suited to tight
+    runs (fewer iterations); at the default tolerance, at short horizons and for entries the caller
+    sets nothing changes.  The tight handle still agrees with the oracle run with the step sizes it
+    reports, iteration for iteration."""
     tight = dict(eps_abs=1e-7, eps_rel=1e-7, max_iter=100000)
-    base = tg.BatchedMPC6(tg.mpc6_params(N=50)).rho
-    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(**tight)).rho == 4.0 * base
-    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(eps_abs=1e-7, eps_rel=1e-3)).rho == base
-    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(rho=base, **tight)).rho == base
-    assert tg.BatchedMPC6(tg.mpc6_params(N=20), tg.make_opts(**tight)).rho == tg.BatchedMPC6(tg.mpc6_params(N=20)).rho
+    scales = lambda N, **kw: tuple(tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(**kw)).get_opts().rho_scale)
+    builtin = scales(50)
+    assert scales(50, **tight) == (96.0, 3.0, 1.0, 2.0) != builtin
+    assert scales(50, eps_abs=1e-7, eps_rel=1e-3) == builtin == scales(50, eps_abs=1e-4, eps_rel=1e-4)
+    assert scales(50, eps_abs=1e-5, eps_rel=1e-5) == (48.0, 3.0, 1.0, 2.0)
+    assert scales(50, rho_scale=(0, 5, 0, 7), **tight) == (96.0, 5.0, 1.0, 7.0)
+    assert scales(20, **tight) == scales(20)
+    assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(**tight)).rho == tg.BatchedMPC6(tg.mpc6_params(N=50)).rho
     N, B = 50, 24
     x0, ref = oracle.synth_mpc6(SEED + 9, N, 0.1, B)
     eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(**tight))
-    slow = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(rho=base, **tight))
+    slow = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(rho_scale=builtin, **tight))
     r, rs = eng.solve_host(x0, ref), slow.solve_host(x0, ref)
     oracle.match_rho_classes(eng.rho_rows())
     ro = oracle.mpc6_batch(oracle.mpc6_params(N=N), oracle.fixed_rho_settings(eng.rho, warm_start=0, **tight), x0, ref)
@@ -256,7 +259,7 @@ def test_automatic_step_size_follows_the_tolerance_at_long_horizons(tg, oracle):
     # two iterates that both pass at eps 1e-7 sit within a few 1e-3 of the optimum on these problems
     assert (rs["status"] == 1).all() and max(_maxabs(r, rs, rs["status"] == 1)) < 1e-2
     assert r["iters"].mean() < rs["iters"].mean()
-    print("N = 50, eps 1e-7: iterations mean %.0f max %d with the automatic step size, %.0f / %d with that of the default tolerance"
+    print("N = 50, eps 1e-7: iterations mean %.0f max %d with the automatic step sizes, %.0f / %d with those of the default tolerance"
           % (r["iters"].mean(), r["iters"].max(), rs["iters"].mean(), rs["iters"].max()))
 
 

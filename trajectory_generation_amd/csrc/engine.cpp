@@ -94,25 +94,31 @@ struct DevStage {
     double *d_warm = nullptr; int warm_cap = 0; bool warm_valid = false; int warm_B = 0;
     double *d_res = nullptr; int res_cap = 0, res_B = 0;
 
-    // The automatic step size is chosen for OSQP's default tolerance, where most instances pass the
-    // first check.  Run tight (eps <= 1e-6: what it takes to land within 1e-4 of the optimum), the long
-    // 6-DOF horizons converge faster with a larger one: at N = 50 and eps 1e-9 four times the step
-    // halves the mean iteration count and cuts the slowest instance from 36 000 to about 8 000
-    // iterations, while at 1e-3 it would double the mean; the short horizons (N = 20: 75 iterations
-    // at 1e-9) and the 12-state stages gain nothing (tools/tight_rho_sweep.py, a held-out seed).
-    // Chosen at create from the tolerances given there, like everything that enters the operators.
-    static double tolerance_rho(const StageModel &mdl, const tg_solver_opts &o, double rho)
+    // The automatic per-class step sizes are chosen for OSQP's default tolerance, where most
+    // instances pass the first check.  Run tight (eps <= 1e-6: what it takes to land within 1e-4 of
+    // the optimum), the long 6-DOF horizons converge several times faster with a much larger step
+    // on the position rows (the altitude floor) and a smaller one on the inputs: at N = 50 and eps
+    // 1e-9 the mean falls from 1 370 to 360 iterations and the slowest of 4096 instances from 37 000
+    // to 4 700, alike at N = 31 ... 60 and from 1e-6 down, while at 1e-3 the same scales would
+    // double the mean; the short horizons (N = 20: 75 iterations at 1e-9) and the 12-state stages
+    // gain nothing (tools/tight_rho_sweep.py, held-out seeds).  Chosen at create from the tolerances
+    // given there, like everything that enters the operators; entries the caller sets are kept.
+    static void tolerance_scales(const StageModel &mdl, const tg_solver_opts &o, double scale[4])
     {
-        if (rho > 0 || mdl.family != TG_FAM_6DOF || mdl.N <= 30) return rho;
+        for (int k = 0; k < 4; k++) scale[k] = o.rho_scale[k];
         const double eps = o.eps_abs > o.eps_rel ? o.eps_abs : o.eps_rel;
-        return (eps > 0 && eps <= 1e-6) ? 4.0 * default_rho(mdl) : rho;
+        if (mdl.family != TG_FAM_6DOF || mdl.N <= 30 || !(eps > 0 && eps <= 1e-5)) return;
+        // in between (eps 1e-5) half that step on the position rows: mean 89 against 114 iterations
+        const double tight[4] = {eps <= 1e-6 ? 96.0 : 48.0, 3.0, 1.0, 2.0};
+        for (int k = 0; k < 4; k++) if (!(scale[k] > 0)) scale[k] = tight[k];
     }
 
     int init(const StageModel &mdl, const tg_solver_opts &o, double rho)
     {
         std::string err;
-        rho = tolerance_rho(mdl, o, rho);
-        if (!build_stage(mdl, rho, o.sigma, o.rho_scale, sp, err)) return fail(TG_E_NUMERIC, err);
+        double scale[4];
+        tolerance_scales(mdl, o, scale);
+        if (!build_stage(mdl, rho, o.sigma, scale, sp, err)) return fail(TG_E_NUMERIC, err);
         int rc;
         if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
         HIP_TRY(hipMalloc((void **)&d_queue, sizeof(int)));
