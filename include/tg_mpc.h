@@ -80,7 +80,8 @@ typedef struct {
      * for all inequality rows and adapts it at run time; a fixed rho per class of row takes
      * the place of that adaptation.  0 = the built-in choice, 1 = OSQP's uniform rho.  The
      * built-in choice is fixed at create and follows the tolerances given there: a 6-DOF handle
-     * with N > 30 created with eps_abs, eps_rel <= 1e-5 takes scales suited to tight runs. */
+     * with N > 30 created with eps_abs, eps_rel <= 1e-5, and the yaw stage of a 12-state handle
+     * with N >= 20 created with eps <= 1e-6, take scales suited to tight runs. */
     double rho_scale[4];
     /* OSQP's eps_prim_inf (1e-4): tolerance of the primal infeasibility certificate tested at
      * every termination check; 0 switches the test off.  Dual infeasibility cannot occur: the

@@ -151,6 +151,8 @@ void qp12_merge(int N, const double *xy_sol, const double *z_sol, const double *
  * positions, velocities, accelerations (12-state) and inputs, and to the XY mixed rows
  * (velocity class for rows 0-3, acceleration class for rows 4-5).  Default {1,1,1,1}. */
 void mpc_set_rho_class_scale(double pos, double vel, double acc, double input);
+/* the same for one family (FAM_*) only: the stages of the 12-state chain may differ */
+void mpc_set_rho_class_scale_family(int family, double pos, double vel, double acc, double input);
 
 /* ------------------------------------------------------------------ whole mpcLoop   */
 

@@ -328,14 +328,21 @@ void qp12_build(const mpc12_params *p, int family, double *P, double *A, double 
 }
 
 /* ---------------------------------------------------------------- per-class rho scale */
-static double g_cls[4] = {1.0, 1.0, 1.0, 1.0};
+/* one set per family: the stages of the 12-state chain may carry different ones */
+static double g_cls_fam[4][4] = {{1.0, 1.0, 1.0, 1.0}, {1.0, 1.0, 1.0, 1.0}, {1.0, 1.0, 1.0, 1.0}, {1.0, 1.0, 1.0, 1.0}};
+void mpc_set_rho_class_scale_family(int family, double pos, double vel, double acc, double input)
+{
+    if (family < 0 || family > 3) return;
+    g_cls_fam[family][0] = pos; g_cls_fam[family][1] = vel; g_cls_fam[family][2] = acc; g_cls_fam[family][3] = input;
+}
 void mpc_set_rho_class_scale(double pos, double vel, double acc, double input)
 {
-    g_cls[0] = pos; g_cls[1] = vel; g_cls[2] = acc; g_cls[3] = input;
+    for (int f = 0; f < 4; f++) mpc_set_rho_class_scale_family(f, pos, vel, acc, input);
 }
 
 static void apply_class_scale(osqp_work *w, int family, int N)
 {
+    const double *g_cls = g_cls_fam[family];
     if (g_cls[0] == 1.0 && g_cls[1] == 1.0 && g_cls[2] == 1.0 && g_cls[3] == 1.0) return;
     int n, m, nx, nu;
     qp_dims(family, N, &n, &m, &nx, &nu);

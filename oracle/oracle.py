@@ -124,6 +124,7 @@ def lib():
         L.mpc12_batch3.argtypes = [C.POINTER(Mpc12Params)] + [C.POINTER(Settings)] * 3 + [C.c_int, _dp, _dp, _dp, _dp, _ip, _ip]
         L.osqp_set_rho_scale.argtypes = [C.c_void_p, _dp]
         L.mpc_set_rho_class_scale.argtypes = [C.c_double] * 4
+        L.mpc_set_rho_class_scale_family.argtypes = [C.c_int] + [C.c_double] * 4
         L.synth_uniform.restype = C.c_double
         L.synth_uniform.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]
         L.synth_mpc6.argtypes = [C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp]
@@ -185,11 +186,15 @@ def set_rho_class_scale(pos=1.0, vel=1.0, acc=1.0, inp=1.0):
 
 def match_rho_classes(stages):
     """Read the per-class multipliers back from per-row rho vectors and make them the ones the
-    oracle uses.  stages: iterable of (rho_vec, rho, nx, N) in the reference's row ordering
-    (dynamics | state box | input box | mixed).  Rows with infinite bounds carry rho_min and say
-    nothing about their class; such a class keeps multiplier 1."""
+    oracle uses.  stages: iterable of (rho_vec, rho, nx, N[, stage]) in the reference's row ordering
+    (dynamics | state box | input box | mixed); stage = "xy" / "z" / "yaw" names the family of a
+    12-state stage (each keeps its own set), without it the set applies to every family.  Rows with
+    infinite bounds carry rho_min and say nothing about their class; such a class keeps multiplier 1."""
+    fams = {"xy": FAM_XY, "z": FAM_Z, "yaw": FAM_YAW}
     cls = [1.0, 1.0, 1.0, 1.0]
-    for rho_vec, rho, nx, N in stages:
+    for st in stages:
+        rho_vec, rho, nx, N = st[:4]
+        cls = [1.0, 1.0, 1.0, 1.0]
         Nx = nx * (N + 1)
         rows = {0: Nx + 0, 3: 2 * Nx}
         if nx == 6 and len(rho_vec) == 2 * Nx + 3 * N:      # 6-DOF: p(3), v(3); only p_z is bounded
@@ -200,7 +205,10 @@ def match_rho_classes(stages):
             f = rho_vec[r] / rho
             if f > 1e-3:
                 cls[k] = float(f)
-    set_rho_class_scale(*cls)
+        if len(st) > 4:
+            lib().mpc_set_rho_class_scale_family(fams[st[4]], *cls)
+        else:
+            set_rho_class_scale(*cls)
     return tuple(cls)
 
 

@@ -247,6 +247,19 @@ def test_automatic_step_sizes_follow_the_tolerance_at_long_horizons(tg, oracle):
     assert scales(50, rho_scale=(0, 5, 0, 7), **tight) == (96.0, 5.0, 1.0, 7.0)
     assert scales(20, **tight) == scales(20)
     assert tg.BatchedMPC6(tg.mpc6_params(N=50), tg.make_opts(**tight)).rho == tg.BatchedMPC6(tg.mpc6_params(N=50)).rho
+    # the 12-state chain: the yaw stage alone, from N = 20 and eps 1e-6
+    s12 = lambda N, stage, **kw: tuple(tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(**kw)).get_opts(stage).rho_scale)
+    assert s12(20, "yaw", **tight) == (1.0, 100.0, 3.0, 1.0) != s12(20, "yaw")
+    assert s12(20, "z", **tight) == s12(20, "z") and s12(20, "xy", **tight) == s12(20, "xy")
+    assert s12(10, "yaw", **tight) == s12(10, "yaw") == s12(20, "yaw", eps_abs=1e-5, eps_rel=1e-5)
+    e12 = tg.BatchedMPC12(tg.mpc12_params(N=20), tg.make_opts(**tight))
+    x, rf = oracle.synth_mpc12(SEED + 10, 20, 0.1, 12)
+    r12 = e12.solve_host(x, rf)
+    oracle.match_rho_classes(e12.rho_rows())        # one set of class multipliers per stage
+    ro12 = oracle.mpc12_batch(oracle.mpc12_params(N=20), {k: oracle.fixed_rho_settings(e12.rho(k), warm_start=0, **tight) for k in ("xy", "z", "yaw")}, x, rf)
+    assert np.array_equal(r12["status"], ro12["status"]) and np.array_equal(r12["iters"], ro12["iters"])
+    ok12 = (ro12["status"] == 1).all(1)
+    assert ok12.sum() >= 6 and max(_maxabs(r12, ro12, ok12)) < 1e-8
     N, B = 50, 24
     x0, ref = oracle.synth_mpc6(SEED + 9, N, 0.1, B)
     eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(**tight))

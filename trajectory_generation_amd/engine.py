@@ -256,7 +256,7 @@ class BatchedMPC12:
 
     def rho_rows(self):
         N = self.params.N
-        return [(self.get(s, capi.TG_VEC_RHO), self.rho(s), 6 if s == "xy" else 3, N) for s in ("xy", "z", "yaw")]
+        return [(self.get(s, capi.TG_VEC_RHO), self.rho(s), 6 if s == "xy" else 3, N, s) for s in ("xy", "z", "yaw")]
 
     def get(self, stage, which):
         n, m = self.dims(stage)
