@@ -30,7 +30,7 @@ def draw_opts(N):
     chk = int(rng.choice([5, 10, 25, 25, 25, 50]))
     fine = int(rng.choice([0, 0, 5])) if chk % 5 == 0 and chk > 5 else 0
     mi = int(rng.choice([1, 2, 4, 160])) * chk
-    eps = float(rng.choice([1e-2, 1e-3, 1e-3, 1e-4, 1e-5]))
+    eps = float(rng.choice([1e-2, 1e-3, 1e-3, 1e-4, 1e-5, 1e-7]))      # 1e-7: the step sizes of the tight tiers
     o = dict(eps_abs=eps, eps_rel=eps * float(rng.choice([1.0, 1.0, 0.1])), alpha=float(rng.choice([1.0, 1.4, 1.6, 1.6, 1.8])),
              sigma=float(rng.choice([1e-6, 1e-6, 1e-4])), max_iter=mi, check_termination=chk, check_fine=fine,
              eps_prim_inf=float(rng.choice([1e-4, 1e-4, 1e-3, 0.0])))
