@@ -60,6 +60,13 @@ def report(tag, trial, desc, r, ro, solved, tol):
         for ix in idx:
             ix = tuple(ix)
             print("      at %s: engine %d after %d, oracle %d after %d" % (ix, r["status"][ix], r["iters"][ix], ro["status"][ix], ro["iters"][ix]))
+        if r["X"].shape[1] % 12 == 0 and r["status"].ndim == 2 and solved.any():
+            # 12-state chain: where the trajectories part (columns x, y | z | yaw of every step).  The yaw
+            # reference is atan2 of the planned XY velocities: where those are next to zero it amplifies
+            # rounding-level differences of the XY solution
+            dX = np.abs(r["X"][solved] - ro["X"][solved]).reshape(int(solved.sum()), -1, 12)
+            print("      max-abs difference of the solved instances: xy %.1e  z %.1e  yaw %.1e" % (
+                dX[:, :, :6].max(), dX[:, :, 6:9].max(), dX[:, :, 9:].max()), flush=True)
 
 
 for trial in range(TRIALS):
