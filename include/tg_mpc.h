@@ -246,7 +246,9 @@ int tg_mpc12_dims(const tg_mpc12 *h, int stage, int *n, int *m);
 int tg_mpc12_get(const tg_mpc12 *h, int stage, int which, double *out);
 double tg_mpc12_rho(const tg_mpc12 *h, int stage);
 int tg_mpc12_kernel_info(const tg_mpc12 *h, int stage, int *mfma_per_tile_iteration, int *lowrank);
-/* as for the 6-DOF handle; get is per stage (their rho differ), set applies to all three */
+/* as for the 6-DOF handle; get is per stage (their rho and rho_scale differ), set applies to all
+ * three.  set ignores rho and rho_scale (per stage, frozen at create), so that what get returned
+ * for any stage can be modified and handed back; only a different sigma is refused. */
 int tg_mpc12_get_opts(const tg_mpc12 *h, int stage, tg_solver_opts *out);
 int tg_mpc12_set_opts(tg_mpc12 *h, const tg_solver_opts *o);
 int tg_mpc12_last_residuals(tg_mpc12 *h, int stage, int B, double *prim, double *dual);

@@ -30,7 +30,7 @@ def test_bench_line_single_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["config"]["workload"] == "mpc_6dof_B262144_N50" and "model" not in d["config"]
     assert d["config"]["horizon_N"] == 50 and d["config"]["instances_total"] == 262144 and d["config"]["check_fine"] == 0
-    assert d["scaling"] == "strong" and d["timed_s"] >= 0.5 and d["timed_steps"] % 5 == 0
+    assert d["scaling"] == "strong" and d["timed_s"] >= 2.0 and d["timed_steps"] % 5 == 0 and d["ranks_seen"] == 1
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     # frac counts the matrix-core flops actually executed: MFMAs per tile-iteration x 2048 / 16 per instance-iteration
@@ -50,13 +50,29 @@ def test_bench_line_single_rank():
     # both sides run to convergence: within the target's 1e-4
     assert par["converged"]["solved_by_both"] >= 0.9 * par["converged"]["instances"] >= 28
     assert par["converged_gpu_vs_converged_osqp_defaults_maxabs"] < par["converged"]["target"] == 1e-4
+    # what a receding-horizon user applies, x(1) and u(0), is part of the whole-horizon figure
+    fs = par["first_step_maxabs"]
+    assert 0 <= fs["gpu_vs_optimum"] <= par["gpu_vs_optimum_maxabs"] and 0 <= fs["gpu_vs_osqp_defaults"] <= par["gpu_vs_osqp_defaults_maxabs"]
+    assert fs["converged_gpu_vs_converged_osqp_defaults"] <= par["converged_gpu_vs_converged_osqp_defaults_maxabs"]
+    # second leg: the rate at the accuracy the target names -- the loosest tolerance whose every entry of
+    # X and U over the whole batch lies within 1e-4 of a converged run, timed over whole batches; an
+    # eighth of the node's target rate (1e6 solves/s on eight GPUs) is the least one GPU must deliver
+    at = d["at_target_accuracy"]
+    assert at["target"] == 1e-4 and at["eps"] is not None and at["eps"] < 1e-3 and at["converged_solved_frac"] == 1.0
+    assert at["max_abs_vs_converged"] <= 1e-4 and at["first_step_maxabs_vs_converged"] <= at["max_abs_vs_converged"]
+    assert at["value"] >= 1.25e5 and at["steps"] >= 3 and at["timed_s"] >= 1.0 and at["solved_frac"] == 1.0
+    assert abs(at["value"] - 262144 / (at["ms_per_step"] * 1e-3)) < 1e-6 * at["value"]
+    assert at["ladder"][-1]["eps"] == at["eps"] and all(l["max_abs_vs_converged"] > 1e-4 for l in at["ladder"][:-1])
+    assert 0 < at["roofline_frac"] < 1 and at["iters_mean"] > d["iters_mean"]
+    pt = par["at_target_accuracy"]
+    assert pt["eps"] == at["eps"] and pt["gpu_vs_converged_osqp_defaults_maxabs"] < 1e-4
 
 
 def test_bench_self_launches_its_ranks():
     """`python bench.py --gpus 2` without a launcher starts its two ranks itself (gloo rehearsal,
     both on GPU 0) and prints one line for the two of them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "10",
-                        "--warmup", "2", "--workload", "mpc_6dof_B4096_N20"],
+                        "--warmup", "2", "--workload", "mpc_6dof_B4096_N20", "--no-target-leg"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     d = _last_json(r.stdout.decode())
@@ -68,7 +84,7 @@ def test_bench_small_batch_line_carries_the_finer_check_schedule_as_a_second_fig
     """mpc_6dof_B4096_N20 keeps OSQP's schedule of checks for its value; the figure with convergence
     also tested every 5 iterations is a second key."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "2",
-                        "--workload", "mpc_6dof_B4096_N20", "--no-cpu-baseline"],
+                        "--workload", "mpc_6dof_B4096_N20", "--no-cpu-baseline", "--no-target-leg"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
     d = _last_json(r.stdout.decode())
     cf = d["check_fine_5"]
@@ -79,7 +95,7 @@ def test_bench_small_batch_line_carries_the_finer_check_schedule_as_a_second_fig
 def test_bench_two_ranks_shard_the_instances():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
-           "--warmup", "1", "--backend", "gloo", "--workload", "mpc_6dof_B32768_N50"]
+           "--warmup", "1", "--backend", "gloo", "--workload", "mpc_6dof_B32768_N50", "--no-target-leg"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
     d = _last_json(r.stdout.decode())
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "cpu_baseline" not in d
@@ -95,8 +111,12 @@ def test_bench_fixed_total_is_shared_out():
            "--warmup", "1", "--backend", "gloo"]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
     d = _last_json(r.stdout.decode())
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["ranks_seen"] == 2
     assert d["config"]["instances_total"] == 262144 and d["config"]["instances_rank0"] == 131072
+    # every rank runs the second leg on its share; the figures are those of the whole batch
+    at = d["at_target_accuracy"]
+    assert at["max_abs_vs_converged"] <= 1e-4 and at["solved_frac"] == 1.0
+    assert abs(at["value"] - 262144 / (at["ms_per_step"] * 1e-3)) < 1e-6 * at["value"]
 
 
 def test_bench_closed_loop_reports_failures_per_step():
@@ -124,7 +144,7 @@ def test_bench_small_batches_are_kept_in_flight():
     out = {}
     for depth in (0, 1):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "2",
-                            "--workload", "mpc_12state_B4096_N20", "--no-cpu-baseline", "--pipeline", str(depth)],
+                            "--workload", "mpc_12state_B4096_N20", "--no-cpu-baseline", "--no-target-leg", "--pipeline", str(depth)],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, cwd=ROOT)
         out[depth] = _last_json(r.stdout.decode())
     a, b = out[0], out[1]

@@ -124,3 +124,23 @@ def test_two_rank_sharding_gloo(tmp_path):
     for pr in procs:
         out, _ = pr.communicate(timeout=180)
         assert pr.returncode == 0, out.decode()
+
+
+def test_bench_launcher_ends_the_other_ranks_when_one_dies():
+    """`python bench.py --gpus 2` supervises its ranks: rank 1 exits early (injected), rank 0 is
+    left waiting for it in the process-group rendezvous; the launcher must end it and return
+    rank 1's status instead of waiting for a time limit."""
+    import subprocess
+    import sys
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TG_BENCH_FAULT_RANK"] = "1"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--workload", "mpc_6dof_B4096_N20"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode == 3, (r.returncode, r.stderr.decode()[-1000:])
+    assert time.time() - t0 < 30
+    err = r.stderr.decode()
+    assert "rank 1 of 2 exited with status 3" in err and "injected failure of rank 1" in err
+    assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]

@@ -136,7 +136,6 @@ struct DevStage {
         HIP_TRY(hipMalloc((void **)&d_queue, sizeof(int)));
         grid_cap = o.grid_cap;
         hard_first = o.hard_first;
-        hard_first = o.hard_first;
         lowrank_mode = o.lowrank;
         if ((rc = upload(sp.q_w, &d_qw))) return rc;
         if ((rc = upload(sp.l_t, &d_lt))) return rc;
@@ -510,7 +509,7 @@ struct DevStage {
             g_pending.push_back({e0, e1, d});
         }
         if (warm) { warm_valid = true; warm_B = a.B; }
-        if (!no_alloc) res_B = a.B;
+        res_B = no_alloc ? 0 : a.B;   // a solve without a residual record leaves none of an earlier one behind
         return TG_OK;
     }
     // residuals of the last solve, host arrays of B doubles each (either may be null)
@@ -1215,8 +1214,12 @@ int tg_mpc12_set_opts(tg_mpc12 *h, const tg_solver_opts *o)
         tg_solver_opts have;
         h->st[f].effective_opts(h->o, &have);
         tg_solver_opts want = *o;
-        want.rho = 0.0;     // the per-stage rho came from rho_xyz or the built-in choice
-        if (!same_operator(have, want)) return fail(TG_E_STATE, "sigma and rho_scale are frozen at create: make a new handle");
+        // rho and the per-class scales are per stage (rho_xyz / the built-in choices, which differ
+        // between the stages) and frozen at create: what tg_mpc12_get_opts returned for any one
+        // stage is accepted for all three, and neither is looked at
+        want.rho = 0.0;
+        for (int k = 0; k < 4; k++) want.rho_scale[k] = 0.0;
+        if (!same_operator(have, want)) return fail(TG_E_STATE, "sigma is frozen at create: make a new handle");
     }
     for (int f = 1; f <= 3; f++) h->st[f].set_run_opts(*o);
     h->o.alpha = o->alpha; h->o.eps_abs = o->eps_abs; h->o.eps_rel = o->eps_rel; h->o.eps_prim_inf = o->eps_prim_inf;
