@@ -200,6 +200,10 @@ void tg_mpc12_destroy(tg_mpc12 *h);
  * Z solve -> computeXYBounds -> XY solve -> computeYawRefTrajectory -> Yaw solve -> merge.
  *   x0  [12][ld], ref [12(N+1)][ld], X [12(N+1)][ld], U [4N][ld]
  *   status[3][ld], iters[3][ld]   rows = {z, xy, yaw} stage   (may be NULL)
+ * X and U of an instance are written only when all three stages end TG_SOLVED -- whole columns
+ * or nothing: mpcLoop fills _x_opt / _u_opt in extractSolution, after the third stage
+ * (mpc_12state.cpp:1405-1449, 1528-1551), so an instance whose XY or yaw stage fails keeps the
+ * whole plan of its last successful call, Z rows included.
  * warm: as above (a deviation from the reference, which cold-starts all three
  * solvers, mpc_12state.cpp:1025,1045,1065; used by closed-loop roll-outs). */
 int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
@@ -212,14 +216,15 @@ int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref,
  * memory at call time -- code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc.  Same three stages, same kernels and bit-identical X / U / status / iters (cold start
  * only: there is no warm argument, no residual record and no kernel timing), but the arrays that
- * pass between the stages (xy_max, mixed_max, yaw_ref), the stage status rows when d_status is NULL
- * and the kernels' queue counters live in a static device array of 16 MiB that every GPU the
- * library runs on holds until the process ends, instead of in buffers the handle allocates.  The
- * call makes no hipMalloc / hipFree.  Limit: tg_mpc12_static_scratch_bytes(N, ld) = 256 +
- * roundup(12 ld, 256) + 8 (13 N + 1) ld must not exceed 16 MiB (N = 20: ld <= 7984; N = 50:
- * ld <= 3216); larger batches are refused with TG_E_ARG.  All calls on one GPU share that GPU's
- * array: two of them overlapping in time (different streams or threads, any handles) race; calls
- * on one stream, or on different GPUs, do not.  tg_mpc12_intermediates does not see its arrays. */
+ * pass between the stages (xy_max, mixed_max, yaw_ref), the stages' solutions until all three have
+ * solved, the stage status rows when d_status is NULL and the kernels' queue counters live in a
+ * static device array of 32 MiB that every GPU the library runs on holds until the process ends,
+ * instead of in buffers the handle allocates.  The call makes no hipMalloc / hipFree.  Limit:
+ * tg_mpc12_static_scratch_bytes(N, ld) = 256 + roundup(12 ld, 256) + 8 (29 N + 13) ld must not
+ * exceed 32 MiB (N = 20: ld <= 7055; N = 50: ld <= 2863); larger batches are refused with
+ * TG_E_ARG.  All calls on one GPU share that GPU's array: two of them overlapping in time
+ * (different streams or threads, any handles) race; calls on one stream, or on different GPUs, do
+ * not.  tg_mpc12_intermediates does not see its arrays. */
 int tg_mpc12_solve_batch_static(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
                                 double *d_X, double *d_U, int *d_status, int *d_iters, void *stream);
 unsigned long long tg_mpc12_static_scratch_bytes(int N, int ld);
@@ -262,8 +267,7 @@ int tg_mpc12_last_residuals(tg_mpc12 *h, int stage, int B, double *prim, double 
  * solve did not reach TG_SOLVED in every stage got no new plan -- mpcLoop returned false and the
  * reference's node publishes nothing (mpc_ros.cpp:428-432, mpc_12state_ros.cpp:519-527) -- so it
  * keeps following the last plan it received: its U rows move one step up (zeros enter at the end:
- * beyond the plan it coasts) before row 0 is applied.  With NULL every instance counts as solved.
- * 12-state: a stage that did solve has already written its own rows of X / U. */
+ * beyond the plan it coasts) before row 0 is applied.  With NULL every instance counts as solved. */
 int tg_mpc6_plant_step(tg_mpc6 *h, int B, int ld, double *d_x0, double *d_U, const int *d_status, void *stream);
 int tg_mpc12_plant_step(tg_mpc12 *h, int B, int ld, double *d_x0, double *d_U, const int *d_status, void *stream);
 /* Receding horizon on a reference array ref [nx(N+1)][ld]: block i+1 moves to block i, the last

@@ -116,6 +116,99 @@ def test_failed_instances_keep_their_columns(tg, oracle):
     assert not (X[:, ~failed] == -3.0).any() if (~failed).any() else True
 
 
+def test_failed_instances_keep_their_columns_12state(tg, oracle):
+    """The 12-state chain writes whole columns or nothing: _x_opt / _u_opt change in extractSolution,
+    after the third stage (mpc_12state.cpp:1405-1449, 1528-1551).  Instance 1092 of the benchmark
+    batch solves its Z stage and fails its XY stage; a second vehicle is made to fail in Z: their
+    sentinel-filled columns survive, Z rows included, and every other column matches the oracle."""
+    import torch
+    N, B, first = 20, 32, 1088
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N)); op = oracle.mpc12_params(N=N)
+    x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B, first)
+    x12[9, 7] = 30.0                                  # vertical speed outside its box: the Z stage is infeasible
+    buf = eng.alloc(B)
+    _to_dev(buf, x12, ref12)
+    for entry in ("solve", "solve_static"):
+        buf["X"].fill_(-3.0); buf["U"].fill_(-3.0)
+        getattr(eng, entry)(buf)
+        torch.cuda.synchronize()
+        st = buf["status"][:, :B].cpu().numpy()
+        X = buf["X"][:, :B].cpu().numpy(); U = buf["U"][:, :B].cpu().numpy()
+        assert tuple(st[:, 4]) == (1, -3, -10) and tuple(st[:, 9]) == (-3, -10, -10)
+        failed = (st != 1).any(0)
+        assert failed.sum() == 2
+        assert (X[:, failed] == -3.0).all() and (U[:, failed] == -3.0).all()
+        assert not (X[:, ~failed] == -3.0).any() and not (U[:, ~failed] == -3.0).any()
+        s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
+        oracle.match_rho_classes(eng.rho_rows())
+        ro = oracle.mpc12_batch(op, s, x12, ref12)
+        np.testing.assert_array_equal(st.T, ro["status"])
+        assert np.abs(X.T[~failed] - ro["X"][~failed]).max() < 1e-8 and np.abs(U.T[~failed] - ro["U"][~failed]).max() < 1e-8
+        assert (ro["X"][failed] == 0).all()          # the oracle's mpcLoop leaves its outputs alone as well
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_closed_loop_12state_with_a_failing_stage_follows_the_last_plan(tg, oracle, warm):
+    """12-state, N = 20, 32 vehicles, 30 receding-horizon steps against the oracle's mpcLoop run one
+    vehicle at a time.  One vehicle's XY stage fails at step 0 (instance 1092: no plan yet, it
+    coasts); another reports a horizontal speed far outside its box from step 5 to step 7, after
+    five good plans: Z solves, XY is infeasible, yaw is not attempted -- the vehicle keeps the whole
+    plan of step 4 and the gated plant applies that plan's next controls, z jerk included."""
+    import torch
+    from trajectory_generation_amd import _capi as capi
+    from trajectory_generation_amd.mpc_12state import MPC12STATE
+    N, B, first, steps, bad = 20, 32, 1088, 30, 17
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N)); op = oracle.mpc12_params(N=N)
+    x0, ref = oracle.synth_mpc12(SEED + 3, N, 0.1, B, first)
+    A = MPC12STATE._blkdiag(*[eng.get(s, capi.TG_MAT_AD) for s in ("xy", "z", "yaw")])
+    Bm = MPC12STATE._blkdiag(*[eng.get(s, capi.TG_MAT_BD) for s in ("xy", "z", "yaw")])
+    buf = eng.alloc(B)
+    _to_dev(buf, x0, ref)
+    eng.reset_warm()
+    states, stats, plans = [], [], []
+    for k in range(steps):
+        if k == 5:
+            buf["x0"][1, bad] = 60.0
+        if k == 8:
+            buf["x0"][1, bad] = 1.0
+        eng.solve(buf, warm=warm)
+        stats.append(buf["status"][:, :B].cpu().numpy().T.copy())
+        plans.append(buf["U"][:, :B].cpu().numpy().T.copy())
+        eng.plant_step(buf)
+        eng.ref_shift(buf)
+        states.append(buf["x0"][:, :B].cpu().numpy().T.copy())
+    torch.cuda.synchronize()
+    for k in (5, 6, 7):
+        assert tuple(stats[k][bad]) == (1, -3, -10)
+        # the plan of step 4, moved one step up by every plant step since the first failure (zeros
+        # enter at the end); the plant step of a solved vehicle leaves its plan where it is
+        np.testing.assert_array_equal(plans[k][bad][:4 * (N - (k - 5))], plans[4][bad][4 * (k - 5):])
+        assert (plans[k][bad][4 * (N - (k - 5)):] == 0).all()
+    assert tuple(stats[0][4]) == (1, -3, -10) and (plans[0][4] == 0).all()
+    oracle.match_rho_classes(eng.rho_rows())
+    worst, failures = 0.0, 0
+    for b in range(B):
+        m = oracle.Mpc12(op, {s: oracle.fixed_rho_settings(eng.rho(s), warm_start=int(warm)) for s in ("xy", "z", "yaw")})
+        x, r, plan = x0[b].copy(), ref[b].copy(), np.zeros(4 * N)
+        for k in range(steps):
+            if b == bad and k == 5:
+                x[1] = 60.0
+            if b == bad and k == 8:
+                x[1] = 1.0
+            res = m.loop(x, r)
+            np.testing.assert_array_equal(res["status"], stats[k][b])
+            if res["ok"]:
+                plan = res["U"].copy()
+            else:
+                failures += 1
+                plan = np.concatenate([plan[4:], np.zeros(4)])
+            x = A @ x + Bm @ plan[:4]
+            rr = r.reshape(N + 1, 12).copy(); last = rr[N] + (rr[N] - rr[N - 1]); rr[:-1] = rr[1:]; rr[N] = last
+            r = rr.ravel()
+            worst = max(worst, np.abs(states[k][b] - x).max())
+    assert failures >= 4 and worst < 1e-6, (failures, worst)
+
+
 def test_forced_lowrank_falls_back_where_no_variant_is_compiled(tg, oracle):
     """lowrank = 1 asks for the low-rank operators wherever possible: at N = 60 no 6-DOF low-rank
     variant is compiled (five cells per thread reach to N = 52) and the dense form is taken instead

@@ -31,9 +31,22 @@ def test_static_entry_point_matches_the_allocating_one():
     from trajectory_generation_amd import synth
     N, ld = 20, 1200
     lib = capi.load()
-    assert lib.tg_mpc12_static_scratch_bytes(N, ld) == 256 + (12 * ld + 255) // 256 * 256 + 8 * (13 * N + 1) * ld
+    assert lib.tg_mpc12_static_scratch_bytes(N, ld) == 256 + (12 * ld + 255) // 256 * 256 + 8 * (29 * N + 13) * ld
     ref_eng = tg.BatchedMPC12(tg.mpc12_params(N=N))
     eng = tg.BatchedMPC12(tg.mpc12_params(N=N))
+    # a handle that has never solved anything: the static entry point must not make it allocate
+    fresh = tg.BatchedMPC12(tg.mpc12_params(N=N))
+    x0, ref = synth.mpc12(SEED + 3, N, 0.1, 200, 0)
+    a, b = ref_eng.alloc(200, ld=ld), fresh.alloc(200, ld=ld)
+    _fill(a, x0, ref); _fill(b, x0, ref)
+    ref_eng.solve(a)                                  # (the runtime loads the kernels' code at their first launch)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    fresh.solve_static(b)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0, "tg_mpc12_solve_batch_static changed the free device memory"
+    for k in ("status", "iters", "X", "U"):
+        assert torch.equal(a[k], b[k]), k
     # first call: 1100 instances including one whose XY stage is infeasible (gated yaw stage);
     # second call, right after it: 300 other instances
     for B, first in ((1100, 1000), (300, 5000)):
@@ -60,9 +73,25 @@ def test_static_entry_point_matches_the_allocating_one():
                                                None, None, None))
     torch.cuda.synchronize()
     assert torch.equal(a["X"], b["X"]) and torch.equal(a["U"], b["U"])
+    # a grid smaller than the batch: the slots are refilled from the queue counters in the static array
+    # (cleared by every call), bit-identical to the allocating path with the same grid
+    for e in (ref_eng, eng):
+        o = e.get_opts("xy")
+        o.grid_cap = 8
+        e.set_opts(o)
+    for B, first in ((1100, 1000), (700, 3000)):
+        x0, ref = synth.mpc12(SEED + 3, N, 0.1, B, first)
+        a, b = ref_eng.alloc(B, ld=ld), eng.alloc(B, ld=ld)
+        _fill(a, x0, ref); _fill(b, x0, ref)
+        ref_eng.solve(a)
+        eng.solve_static(b)
+        torch.cuda.synchronize()
+        for k in ("status", "iters", "X", "U"):
+            assert torch.equal(a[k], b[k]), (B, k, "queue")
+        assert ((b["status"][:, :B] == 1).all(0)).double().mean().item() > 0.99
     # beyond the static array: refused, nothing launched, the allocating entry point still serves it
     big_ld = 8192
-    assert lib.tg_mpc12_static_scratch_bytes(N, big_ld) > 16 << 20
+    assert lib.tg_mpc12_static_scratch_bytes(N, big_ld) > 32 << 20
     c = eng.alloc(big_ld, ld=big_ld)
     with pytest.raises(capi.TgError) as e:
         eng.solve_static(c)

@@ -1540,6 +1540,29 @@ __global__ __launch_bounds__(256) void yaw_ref_kernel(int B, int ld, int N,
     yaw_ref[(size_t)i * ld + inst] = atan2(yt - yi, xt - xi);
 }
 
+// ---------------------------------------------------------------- merge of the 12-state chain
+// MPC12STATE::extractSolution (mpc_12state.cpp:1528-1551) runs after the third stage has solved, so
+// _x_opt / _u_opt change only when all three did (mpcLoop returns at the first failing stage,
+// :1405-1449).  The stages leave their solutions in Xs / Us; rows [r0, r0 + rows_per_block) of the
+// stacked [X; U] of every instance with three "solved" statuses go to the caller's arrays, the
+// columns of the other instances are left as they are.
+__global__ __launch_bounds__(256) void merge12_kernel(int B, int ld, int rowsX, int rowsU, int rows_per_block,
+                                                       const double *__restrict__ Xs, const double *__restrict__ Us,
+                                                       const int *__restrict__ status,
+                                                       double *__restrict__ X, double *__restrict__ U)
+{
+    const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+    if (inst >= B) return;
+    const bool ok = status[inst] == TG_DEV_SOLVED && status[(size_t)ld + inst] == TG_DEV_SOLVED &&
+                    status[(size_t)2 * ld + inst] == TG_DEV_SOLVED;
+    if (!ok) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, rowsX + rowsU);
+    for (int r = r0; r < r1; r++) {
+        if (r < rowsX) X[(size_t)r * ld + inst] = Xs[(size_t)r * ld + inst];
+        else U[(size_t)(r - rowsX) * ld + inst] = Us[(size_t)(r - rowsX) * ld + inst];
+    }
+}
+
 // ---------------------------------------------------------------- closed-loop roll-out helpers
 // Plant update with the first control of the horizon, x0 <- A x0 + B u(0): the rule the reference's
 // test mains roll the solution out with (test_mpc_6dof.cpp:115-122, test_mpc_12state.cpp:193-197).
@@ -1980,6 +2003,15 @@ hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double 
 {
     dim3 grid((B + 255) / 256, N + 1);
     hipLaunchKernelGGL(yaw_ref_kernel, grid, dim3(256), 0, s, B, ld, N, ref, X, yaw_ref);
+    return hipGetLastError();
+}
+
+hipError_t launch_merge12(int B, int ld, int N, const double *Xs, const double *Us, const int *status, double *X,
+                          double *U, hipStream_t s)
+{
+    const int rowsX = 12 * (N + 1), rowsU = 4 * N, rpb = 32;
+    dim3 grid((B + 255) / 256, (rowsX + rowsU + rpb - 1) / rpb);
+    hipLaunchKernelGGL(merge12_kernel, grid, dim3(256), 0, s, B, ld, rowsX, rowsU, rpb, Xs, Us, status, X, U);
     return hipGetLastError();
 }
 

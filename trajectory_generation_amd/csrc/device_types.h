@@ -16,7 +16,7 @@ constexpr int kMaxAxes = 3, kMaxSlots = 4;
 constexpr int kAdmmWaves = 8;           // waves of an ADMM workgroup
 constexpr int kMaxItems = 8;                                        // MFMA work items per wave
 constexpr int kRingDepth = 8;   // operator fragments (k steps) a wave keeps in flight from L2
-constexpr size_t kStaticScratchBytes = (size_t)16 << 20;   // per-GPU static scratch of the entry point that may not allocate
+constexpr size_t kStaticScratchBytes = (size_t)32 << 20;   // per-GPU static scratch of the entry point that may not allocate
 
 // One QP stage as the ADMM kernel sees it.  Every axis of the model is a chain of
 // integrators of order D (6-DOF: D = 2, states p,v, input a; 12-state stages: D = 3,

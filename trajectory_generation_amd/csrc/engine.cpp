@@ -24,6 +24,8 @@ hipError_t launch_plant_step(int nx, int nu, int N, const double *A, const doubl
 hipError_t launch_ref_shift(int B, int ld, int nx, int N, double *ref, hipStream_t s);
 hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
                           hipStream_t s);
+hipError_t launch_merge12(int B, int ld, int N, const double *Xs, const double *Us, const int *status, double *X,
+                          double *U, hipStream_t s);
 hipError_t static_scratch_init(int dev);
 void *static_scratch_ptr(int dev);
 } // namespace tg
@@ -850,6 +852,7 @@ int tg_mpc6_last_residuals(tg_mpc6 *h, int B, double *prim, double *dual)
 // static scratch array.
 struct InterView {
     double *xy_max = nullptr, *mixed_max = nullptr, *yaw_ref = nullptr;
+    double *Xs = nullptr, *Us = nullptr;           // the stages' solutions until all three have solved: [12(N+1)][ld], [4N][ld]
     int ld = 0;
     int *queue[3] = {nullptr, nullptr, nullptr};   // per stage slot (z, xy, yaw); null: the stage's own counter
     bool no_alloc = false;
@@ -859,14 +862,16 @@ struct tg_mpc12 {
     tg_mpc12_params p; tg_solver_opts o; int device;
     DevStage st[4]; // indexed by TG_FAM_*; [0] unused
     HostStaging hs;
-    double *d_inter = nullptr; int inter_ld = 0; // xy_max [6N] | mixed_max [6N] | yaw_ref [N+1]
+    // xy_max [6N] | mixed_max [6N] | yaw_ref [N+1] | stage status (2 rows) | Xs [12(N+1)] | Us [4N]
+    double *d_inter = nullptr; int inter_ld = 0;
     int ensure_inter(int ld)
     {
         if (ld <= inter_ld) return TG_OK;
         hipFree(d_inter); d_inter = nullptr; inter_ld = 0;
-        // + 2 rows holding the [3][ld] stage status used to gate the later stages when the
-        // caller passes no status array
-        HIP_TRY(hipMalloc((void **)&d_inter, (size_t)(13 * p.N + 1 + 2) * ld * sizeof(double)));
+        // 2 rows hold the [3][ld] stage status used to gate the later stages when the caller
+        // passes no status array; Xs / Us take the stages' solutions, which reach the caller's
+        // X / U only for instances whose three stages all solved (launch_merge12)
+        HIP_TRY(hipMalloc((void **)&d_inter, (size_t)(13 * p.N + 1 + 2 + 12 * (p.N + 1) + 4 * p.N) * ld * sizeof(double)));
         inter_ld = ld;
         return TG_OK;
     }
@@ -874,6 +879,8 @@ struct tg_mpc12 {
     double *xy_max() { return d_inter; }
     double *mixed_max() { return d_inter + (size_t)6 * p.N * inter_ld; }
     double *yaw_ref() { return d_inter + (size_t)12 * p.N * inter_ld; }
+    double *plan_X() { return d_inter + (size_t)(13 * p.N + 1 + 2) * inter_ld; }
+    double *plan_U() { return plan_X() + (size_t)12 * (p.N + 1) * inter_ld; }
     InterView view();
 };
 
@@ -881,6 +888,7 @@ InterView tg_mpc12::view()
 {
     InterView iv;
     iv.xy_max = xy_max(); iv.mixed_max = mixed_max(); iv.yaw_ref = yaw_ref(); iv.ld = inter_ld;
+    iv.Xs = plan_X(); iv.Us = plan_U();
     return iv;
 }
 
@@ -924,11 +932,30 @@ void tg_mpc12_destroy(tg_mpc12 *h)
     delete h;
 }
 
+// The three stages of one MPC12STATE::mpcLoop and the merge.  The stages write their solutions to
+// iv.Xs / iv.Us; the caller's X / U receive them only for instances whose three stages all
+// solved: mpcLoop fills _x_opt / _u_opt in extractSolution, after the last stage
+// (mpc_12state.cpp:1405-1449, 1528-1551), so a vehicle whose XY or yaw stage fails keeps the whole
+// plan of its last successful call, Z rows included.
+static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int ld, const double *d_x0, const double *d_ref,
+                       double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s,
+                       bool gated);
+static int mpc12_chain(tg_mpc12 *h, const InterView &iv, int B, int ld, const double *d_x0, const double *d_ref,
+                       double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s)
+{
+    int rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
+    HIP_TRY(launch_merge12(B, ld, h->p.N, iv.Xs, iv.Us, d_status, d_X, d_U, s));
+    return TG_OK;
+}
+
 // gated: instances whose upstream stage did not solve are skipped (status TG_UNSOLVED), as
 // MPC12STATE::mpcLoop returns at the first failing stage (mpc_12state.cpp:1374-1453)
 static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int ld, const double *d_x0, const double *d_ref,
                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s,
-                       bool gated = false)
+                       bool gated)
 {
     const tg_mpc12_params &p = h->p;
     if (iv.ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
@@ -971,22 +998,18 @@ int tg_mpc12_solve_batch(tg_mpc12 *h, int B, int ld, const double *d_x0, const d
     hipStream_t s = (hipStream_t)stream;
     if ((rc = h->ensure_inter(ld))) return rc;
     if (!d_status) d_status = h->own_status();
-    const InterView iv = h->view();
-    if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s, true))) return rc;
-    return TG_OK;
+    return mpc12_chain(h, h->view(), B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, warm, s);
 }
 
 // The same three stages with every piece of device memory beyond the caller's arrays taken from
 // the device's static scratch array: [3 queue counters, 64 B apart | status 3 x ld ints | xy_max 6N x ld |
-// mixed_max 6N x ld | yaw_ref (N+1) x ld doubles].  Nothing here allocates: no hipMalloc / hipFree, no
-// warm start, no residual record, no timing events.
+// mixed_max 6N x ld | yaw_ref (N+1) x ld | Xs 12(N+1) x ld | Us 4N x ld doubles].  Nothing here allocates:
+// no hipMalloc / hipFree, no warm start, no residual record, no timing events.
 unsigned long long tg_mpc12_static_scratch_bytes(int N, int ld)
 {
     if (N < 1 || ld < 1) return 0;
     const unsigned long long status = ((unsigned long long)3 * ld * sizeof(int) + 255) / 256 * 256;
-    return 256 + status + (unsigned long long)(13 * (unsigned long long)N + 1) * ld * sizeof(double);
+    return 256 + status + (unsigned long long)(13 * (unsigned long long)N + 1 + 12 * ((unsigned long long)N + 1) + 4 * (unsigned long long)N) * ld * sizeof(double);
 }
 
 int tg_mpc12_solve_batch_static(tg_mpc12 *h, int B, int ld, const double *d_x0, const double *d_ref,
@@ -1011,12 +1034,10 @@ int tg_mpc12_solve_batch_static(tg_mpc12 *h, int B, int ld, const double *d_x0, 
     iv.xy_max = (double *)(base + 256 + status_bytes);
     iv.mixed_max = iv.xy_max + (size_t)6 * h->p.N * ld;
     iv.yaw_ref = iv.mixed_max + (size_t)6 * h->p.N * ld;
+    iv.Xs = iv.yaw_ref + (size_t)(h->p.N + 1) * ld;
+    iv.Us = iv.Xs + (size_t)12 * (h->p.N + 1) * ld;
     if (!d_status) d_status = own_status;
-    hipStream_t s = (hipStream_t)stream;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, s, true))) return rc;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, s, true))) return rc;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, s, true))) return rc;
-    return TG_OK;
+    return mpc12_chain(h, iv, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, (hipStream_t)stream);
 }
 
 int tg_mpc12_solve_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_x0, const double *d_ref,
@@ -1028,7 +1049,7 @@ int tg_mpc12_solve_stage(tg_mpc12 *h, int stage, int B, int ld, const double *d_
     HIP_TRY(hipSetDevice(h->device));
     if (h->inter_ld != 0 && h->inter_ld != ld) { hipFree(h->d_inter); h->d_inter = nullptr; h->inter_ld = 0; }
     if ((rc = h->ensure_inter(ld))) return rc;
-    return mpc12_stage(h, h->view(), stage, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, (hipStream_t)stream);
+    return mpc12_stage(h, h->view(), stage, B, ld, d_x0, d_ref, d_X, d_U, d_status, d_iters, 0, (hipStream_t)stream, false);
 }
 
 int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref, double *X, double *U,

@@ -292,7 +292,7 @@ class BatchedMPC12:
 
     def solve_static(self, buf, stream=None, B=None):
         """solve() for callers that cannot allocate device memory: cold start, inter-stage arrays in
-        the library's static device scratch (16 MiB per GPU; larger batches raise TgError)."""
+        the library's static device scratch (32 MiB per GPU; larger batches raise TgError)."""
         B = buf["B"] if B is None else B
         ld, N = buf["ld"], self.N
         torch = _torch()
