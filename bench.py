@@ -52,7 +52,7 @@ PROFILE_ROUND = "r03"
 TARGET_ACC = 1e-4
 TARGET_LADDER = (1e-6, 3e-7, 1e-7, 3e-8, 1e-8, 3e-9, 1e-9, 3e-10)
 CONVERGED_EPS = 1e-11
-TARGET_MAX_ITER = 20000        # iteration budget of that leg (the reference leaves OSQP at 4000)
+TARGET_MAX_ITER = 4000         # iteration budget of that leg: what the reference leaves OSQP at
 TARGET_MIN_TIMED_S, TARGET_MIN_STEPS = 1.0, 3
 TIGHT_EPS, TIGHT_SAMPLE = 1e-9, 64   # parity figures: both sides run to convergence on this many instances
 
@@ -102,7 +102,7 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=0, smoothing=False, stress=False,
+def cpu_baseline(model, N, seed_off, eps, rho, eng, check=25, check_fine=0, smoothing=False, stress=False,
                  max_iter=4000):
     """Reference CPU path restated: the OSQP algorithm with its default settings and a sparse LDL'
     of the KKT matrix, (a) one instance at a time on one core, as the reference runs it, and (b) one
@@ -136,16 +136,18 @@ def cpu_baseline(model, N, seed_off, eps, rho, rho_rows, check=25, check_fine=0,
         return r, dt
 
     O.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)             # OSQP: one rho for all inequality rows
+    O.set_rho_phases(None)
     osqp = O.default_settings(warm_start=0, eps_abs=eps, eps_rel=eps, max_iter=max_iter, linsys=1)
     t = time.perf_counter(); r1 = run(osqp, 0, single); dt1 = time.perf_counter() - t
     rall, dtall = parallel(osqp)
     # the engine's own algorithm (fixed per-class step sizes, shared factorisation) on one core
-    O.match_rho_classes(rho_rows)
+    O.match_engine(eng)
     fixed = lambda r: O.fixed_rho_settings(r, warm_start=0, eps_abs=eps, eps_rel=eps, check_termination=check,
                                            check_fine=check_fine, max_iter=max_iter, linsys=1)
     s_eng = fixed(rho) if model == "6dof" else {k: fixed(rho[i]) for i, k in enumerate(("xy", "z", "yaw"))}
     t = time.perf_counter(); re = run(s_eng, 0, single); dte = time.perf_counter() - t
     O.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    O.set_rho_phases(None)
     # the same OSQP-default path run to a tight tolerance on the first TIGHT_SAMPLE instances: what its
     # solutions converge to (for the parity figures; not timed)
     rt, _ = parallel(O.default_settings(warm_start=0, eps_abs=TIGHT_EPS, eps_rel=TIGHT_EPS, max_iter=100000, linsys=1),
@@ -581,7 +583,7 @@ def main():
         del e2
     if not args.no_cpu_baseline and world == 1:
         rho = out["config"]["rho"]
-        base, smp = cpu_baseline(model, N, seed_off, args.eps, rho, eng.rho_rows(), args.check, args.check_fine,
+        base, smp = cpu_baseline(model, N, seed_off, args.eps, rho, eng, args.check, args.check_fine,
                                  args.smoothing, args.stress, args.max_iter)
         if closed:
             base["sample"] += "; cold-started single solves of the first step's problems (the closed-loop GPU steps " \

@@ -78,10 +78,8 @@ typedef struct {
     /* multipliers of rho on the box rows of positions, velocities, accelerations (12-state)
      * and inputs; the XY mixed rows use the velocity / acceleration entries.  OSQP has one rho
      * for all inequality rows and adapts it at run time; a fixed rho per class of row takes
-     * the place of that adaptation.  0 = the built-in choice, 1 = OSQP's uniform rho.  The
-     * built-in choice is fixed at create and follows the tolerances given there: a 6-DOF handle
-     * with N > 30 created with eps_abs, eps_rel <= 1e-5, and the yaw stage of a 12-state handle
-     * with N >= 20 created with eps <= 1e-6, take scales suited to tight runs. */
+     * the place of that adaptation (together with the schedule below).  0 = the built-in choice,
+     * 1 = OSQP's uniform rho. */
     double rho_scale[4];
     /* OSQP's eps_prim_inf (1e-4): tolerance of the primal infeasibility certificate tested at
      * every termination check; 0 switches the test off.  Dual infeasibility cannot occur: the
@@ -116,6 +114,19 @@ typedef struct {
      * started last they would leave the GPU waiting for them; -1: batch order.  An instance's
      * result does not depend on it. */
     int    hard_first;
+    /* Step-size schedule, in place of OSQP's run-time rho adaptation.  A handle holds up to three
+     * factorised operators; an instance that is still running at the first termination check at
+     * or after iteration phase_iters[p] (p = 0, 1) continues under the next one, its iterates
+     * (x, z, y) carried over -- any rho is a valid ADMM step, which is what OSQP's own adaptation
+     * relies on.  Decided per instance, at the check; instances that move are gathered and solved
+     * together, so the operator stays shared.  phase_scale[p] multiplies the first operator's
+     * rho_scale for phase p + 1.  phase_iters: 0 = the built-in choice (6-DOF: 100 and 200 with
+     * the step on the position rows x 8 and x 64; 12-state stages: see tg_mpc12_get_opts),
+     * < 0 = no such phase; phase_scale entries of 0 = built-in.  Frozen at create (the operators
+     * are built there); tg_*_set_opts ignores both.  The entry point that allocates nothing runs
+     * the first operator only. */
+    int    phase_iters[2];
+    double phase_scale[2][4];
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

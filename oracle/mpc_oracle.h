@@ -82,6 +82,11 @@ int  osqp_update_lin_cost(osqp_work *w, const double *q);
 /* Extension used by the engine's fixed-rho mode: rho of inequality row i becomes
  * scale[i] * rho (OSQP itself only distinguishes equality / inequality / unbounded rows). */
 int  osqp_set_rho_scale(osqp_work *w, const double *scale);
+/* Step-size schedule of the engine's fixed-rho mode (tg_solver_opts::phase_iters / phase_scale):
+ * nphase <= 3 phases; phase p >= 1 takes over at the first termination check at or after
+ * iteration start[p] for an instance still running, with per-row multipliers scale[p * m + i] on
+ * the inequality rows; x, z, y carry over.  nphase <= 1 switches the schedule off. */
+int  osqp_set_rho_phases(osqp_work *w, int nphase, const int *start, const double *scale);
 void osqp_warm_start(osqp_work *w, const double *x, const double *y);
 int  osqp_solve(osqp_work *w); /* returns status */
 void osqp_get_solution(const osqp_work *w, double *x, double *y);
@@ -153,6 +158,10 @@ void qp12_merge(int N, const double *xy_sol, const double *z_sol, const double *
 void mpc_set_rho_class_scale(double pos, double vel, double acc, double input);
 /* the same for one family (FAM_*) only: the stages of the 12-state chain may differ */
 void mpc_set_rho_class_scale_family(int family, double pos, double vel, double acc, double input);
+/* Step-size schedule for the solvers mpc6_create / mpc12_create make afterwards: nphase (1 .. 3)
+ * phases for one family; start[p] and the class multipliers cls[p][4] (absolute, like
+ * mpc_set_rho_class_scale) of phases 1 .. nphase - 1; phase 0 uses the family's class scale. */
+void mpc_set_rho_phases_family(int family, int nphase, const int *start, const double *cls);
 
 /* ------------------------------------------------------------------ whole mpcLoop   */
 

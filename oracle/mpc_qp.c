@@ -340,14 +340,27 @@ void mpc_set_rho_class_scale(double pos, double vel, double acc, double input)
     for (int f = 0; f < 4; f++) mpc_set_rho_class_scale_family(f, pos, vel, acc, input);
 }
 
-static void apply_class_scale(osqp_work *w, int family, int N)
+/* schedule of later phases per family: start iteration and absolute class multipliers */
+static int g_nphase[4] = {1, 1, 1, 1};
+static int g_phase_start[4][3];
+static double g_phase_cls[4][3][4];
+void mpc_set_rho_phases_family(int family, int nphase, const int *start, const double *cls)
 {
-    const double *g_cls = g_cls_fam[family];
-    if (g_cls[0] == 1.0 && g_cls[1] == 1.0 && g_cls[2] == 1.0 && g_cls[3] == 1.0) return;
+    if (family < 0 || family > 3) return;
+    if (nphase < 1 || nphase > 3) nphase = 1;
+    g_nphase[family] = nphase;
+    for (int p = 1; p < nphase; p++) {
+        g_phase_start[family][p] = start[p];
+        for (int k = 0; k < 4; k++) g_phase_cls[family][p][k] = cls[p * 4 + k];
+    }
+}
+
+/* per-row multipliers of one set of class multipliers */
+static void class_rows(int family, int N, const double *g_cls, double *sc)
+{
     int n, m, nx, nu;
     qp_dims(family, N, &n, &m, &nx, &nu);
     int Nx = nx * (N + 1), Nu = nu * N;
-    double *sc = (double *)calloc(m, sizeof(double));
     for (int r = 0; r < m; r++) sc[r] = 1.0;
     for (int i = 0; i <= N; i++)
         for (int a = 0; a < nx; a++) {
@@ -356,7 +369,22 @@ static void apply_class_scale(osqp_work *w, int family, int N)
         }
     for (int r = 0; r < Nu; r++) sc[2 * Nx + r] = g_cls[3];
     for (int r = 2 * Nx + Nu; r < m; r++) sc[r] = g_cls[(r - 2 * Nx - Nu) % 6 < 4 ? 1 : 2];
-    osqp_set_rho_scale(w, sc);
+}
+
+static void apply_class_scale(osqp_work *w, int family, int N)
+{
+    const double *g_cls = g_cls_fam[family];
+    const int np = g_nphase[family];
+    if (np <= 1 && g_cls[0] == 1.0 && g_cls[1] == 1.0 && g_cls[2] == 1.0 && g_cls[3] == 1.0) return;
+    int n, m, nx, nu;
+    qp_dims(family, N, &n, &m, &nx, &nu);
+    double *sc = (double *)calloc((size_t)m * 3, sizeof(double));
+    class_rows(family, N, g_cls, sc);
+    if (np <= 1) osqp_set_rho_scale(w, sc);
+    else {
+        for (int p = 1; p < np; p++) class_rows(family, N, g_phase_cls[family][p], sc + (size_t)p * m);
+        osqp_set_rho_phases(w, np, g_phase_start[family], sc);
+    }
     free(sc);
 }
 

@@ -125,6 +125,7 @@ def lib():
         L.osqp_set_rho_scale.argtypes = [C.c_void_p, _dp]
         L.mpc_set_rho_class_scale.argtypes = [C.c_double] * 4
         L.mpc_set_rho_class_scale_family.argtypes = [C.c_int] + [C.c_double] * 4
+        L.mpc_set_rho_phases_family.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.synth_uniform.restype = C.c_double
         L.synth_uniform.argtypes = [C.c_ulonglong, C.c_ulonglong, C.c_ulonglong]
         L.synth_mpc6.argtypes = [C.c_ulonglong, C.c_int, C.c_double, C.c_int, C.c_int, _dp, _dp]
@@ -180,8 +181,10 @@ def mpc12_params(N=20, dt=0.1, enable_control_smoothing=False,
 
 
 def set_rho_class_scale(pos=1.0, vel=1.0, acc=1.0, inp=1.0):
-    """Per-class multipliers of rho used by Mpc6 / Mpc12 / mpc*_batch objects created afterwards."""
+    """Per-class multipliers of rho used by Mpc6 / Mpc12 / mpc*_batch objects created afterwards.
+    Also switches the step-size schedule off (match_engine sets both)."""
     lib().mpc_set_rho_class_scale(pos, vel, acc, inp)
+    set_rho_phases(None)
 
 
 def match_rho_classes(stages):
@@ -210,6 +213,36 @@ def match_rho_classes(stages):
         else:
             set_rho_class_scale(*cls)
     return tuple(cls)
+
+
+def set_rho_phases(family=None, starts=(), classes=()):
+    """Step-size schedule of the solvers created afterwards: phases 1.. start at iterations `starts`
+    with absolute class multipliers `classes` (one 4-tuple each); family None = every family.
+    No starts: schedule off."""
+    n = 1 + len(starts)
+    st = (C.c_int * 3)(0, *[int(v) for v in starts])
+    cl = (C.c_double * 12)(*([0.0] * 4 + [float(v) for c in classes for v in c]))
+    for f in ((FAM_6DOF, FAM_XY, FAM_Z, FAM_YAW) if family is None else (family,)):
+        lib().mpc_set_rho_phases_family(f, n, st, cl)
+
+
+def match_engine(eng):
+    """Make the oracle's fixed-rho mode run the step sizes of an engine handle (BatchedMPC6 /
+    BatchedMPC12): the class multipliers of the first operator and the schedule of the later ones
+    (tg_solver_opts::phase_iters / phase_scale as the handle resolved them)."""
+    cls = match_rho_classes(eng.rho_rows())
+    fams = {"xy": FAM_XY, "z": FAM_Z, "yaw": FAM_YAW}
+    stages = [None] if not hasattr(eng, "STAGES") else ["xy", "z", "yaw"]
+    for st in stages:
+        o = eng.get_opts() if st is None else eng.get_opts(st)
+        base = [float(v) for v in o.rho_scale]
+        starts = [int(o.phase_iters[p]) for p in range(2) if o.phase_iters[p] > 0]
+        classes = [[base[k] * float(o.phase_scale[p][k]) for k in range(4)] for p in range(len(starts))]
+        # the engine moves an instance at the first check at or after the iteration asked for
+        chk = int(o.check_termination)
+        starts = [(v + chk - 1) // chk * chk for v in starts]
+        set_rho_phases(None if st is None else fams[st], starts, classes)
+    return cls
 
 
 def dims(family, N):

@@ -66,6 +66,11 @@ struct osqp_work {
     double *sol_x, *sol_y;
     int iter, status, rho_updates;
     double pri_res, dua_res;
+    /* step-size schedule of the engine's fixed-rho mode (osqp_set_rho_phases): per phase a per-row
+       multiplier of rho on the inequality rows and the iteration it starts at; factor of every
+       phase kept (dense mode) so that moving between them costs a pointer swap */
+    int nphase, phase, phase_start[3];
+    double *phase_scale[3], *phase_L[3];
 };
 
 /* ---------------------------------------------------------------- small helpers */
@@ -533,6 +538,7 @@ void osqp_cleanup(osqp_work *w)
     free(w->delta_x); free(w->delta_y); free(w->Ax); free(w->Px); free(w->Aty); free(w->wn);
     free(w->wm); free(w->sol_x); free(w->sol_y);
     kkt_free(w->kkt); free(w->kkt_rhs);
+    for (int p = 0; p < 3; p++) { free(w->phase_scale[p]); free(w->phase_L[p]); }
     free(w);
 }
 
@@ -547,7 +553,11 @@ int osqp_update_bounds(osqp_work *w, const double *l, const double *u)
         int t = classify(w, i);
         if (t != w->constr_type[i]) { w->constr_type[i] = t; changed = 1; }
     }
-    if (changed) { apply_rho(w); if (factor(w)) return 2; }
+    if (changed) {
+        for (int p = 0; p < 3; p++) { free(w->phase_L[p]); w->phase_L[p] = NULL; }   /* factors kept per phase are stale */
+        apply_rho(w);
+        if (factor(w)) return 2;
+    }
     return 0;
 }
 
@@ -564,6 +574,47 @@ int osqp_set_rho_scale(osqp_work *w, const double *scale)
     memcpy(w->rho_scale, scale, sizeof(double) * w->m);
     apply_rho(w);
     return factor(w);
+}
+
+/* An instance that is still running at the first termination check at or after iteration
+ * start[p] continues with rho_scale = scale + p * m on its inequality rows (p = 1 .. nphase - 1;
+ * phase 0 starts every solve).  x, z and y carry over unchanged, as in OSQP's own update_rho.
+ * Mirrors the engine's tg_solver_opts::phase_iters / phase_scale. */
+static void apply_phase(osqp_work *w, int p);
+int osqp_set_rho_phases(osqp_work *w, int nphase, const int *start, const double *scale)
+{
+    for (int p = 0; p < 3; p++) {
+        free(w->phase_scale[p]); free(w->phase_L[p]);
+        w->phase_scale[p] = NULL; w->phase_L[p] = NULL;
+    }
+    w->nphase = 0; w->phase = 0;
+    if (nphase <= 1) return 0;
+    if (nphase > 3) return 1;
+    for (int p = 0; p < nphase; p++) {
+        w->phase_start[p] = p ? start[p] : 0;
+        w->phase_scale[p] = dalloc(w->m);
+        memcpy(w->phase_scale[p], scale + (size_t)p * w->m, sizeof(double) * w->m);
+    }
+    w->nphase = nphase;
+    w->phase = -1;
+    apply_phase(w, 0);
+    return 0;
+}
+
+static void apply_phase(osqp_work *w, int p)
+{
+    if (w->phase == p) return;
+    if (!w->rho_scale) w->rho_scale = dalloc(w->m);
+    /* keep the factor of the phase that is left (dense mode) */
+    if (!w->kkt && w->phase >= 0 && !w->phase_L[w->phase]) {
+        w->phase_L[w->phase] = dalloc(w->n * w->n);
+        memcpy(w->phase_L[w->phase], w->L, sizeof(double) * (size_t)w->n * w->n);
+    }
+    memcpy(w->rho_scale, w->phase_scale[p], sizeof(double) * w->m);
+    apply_rho(w);
+    if (!w->kkt && w->phase_L[p]) memcpy(w->L, w->phase_L[p], sizeof(double) * (size_t)w->n * w->n);
+    else factor(w);
+    w->phase = p;
 }
 
 void osqp_warm_start(osqp_work *w, const double *x, const double *y)
@@ -717,6 +768,7 @@ int osqp_solve(osqp_work *w)
     }
     w->status = ORACLE_UNSOLVED;
     w->rho_updates = 0;
+    if (w->nphase > 1) apply_phase(w, 0);
     int iter, checked = 0;
     for (iter = 1; iter <= w->s.max_iter; iter++) {
         memcpy(w->x_prev, w->x, sizeof(double) * n);
@@ -761,6 +813,12 @@ int osqp_solve(osqp_work *w)
                own schedule has a check */
             int full = w->s.check_fine <= 0 || iter % w->s.check_termination == 0 || iter == w->s.max_iter;
             if (check_termination_ex(w, 0, full)) break;
+            /* step-size schedule: still running at the first check at or after a phase's start */
+            if (w->nphase > 1 && iter < w->s.max_iter) {
+                int p = w->phase;
+                while (p + 1 < w->nphase && iter >= w->phase_start[p + 1]) p++;
+                if (p != w->phase) { apply_phase(w, p); w->rho_updates++; }
+            }
         }
         if (w->s.adaptive_rho && w->s.adaptive_rho_interval &&
             (iter % w->s.adaptive_rho_interval == 0)) {

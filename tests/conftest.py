@@ -22,11 +22,14 @@ def _oracle_module():
 
 @pytest.fixture
 def oracle(_oracle_module):
-    # the per-class rho multipliers are process-global in the oracle: every test starts from
-    # OSQP's uniform rho and opts in to an engine's multipliers with match_rho_classes()
+    # the per-class rho multipliers and the step-size schedule are process-global in the oracle:
+    # every test starts from OSQP's uniform rho without a schedule and opts in to an engine's step
+    # sizes with match_engine()
     _oracle_module.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    _oracle_module.set_rho_phases(None)
     yield _oracle_module
     _oracle_module.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    _oracle_module.set_rho_phases(None)
 
 
 @pytest.fixture(scope="session")

@@ -21,7 +21,7 @@ def test_every_horizon_matches_the_oracle(oracle):
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N))
         x0, ref = oracle.synth_mpc6(11, N, 0.1, B)
         r = eng.solve_host(x0, ref)
-        oracle.match_rho_classes(eng.rho_rows())
+        oracle.match_engine(eng)
         ro = oracle.mpc6_batch(oracle.mpc6_params(N=N), oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
         np.testing.assert_array_equal(r["status"], ro["status"], err_msg="6-DOF N=%d" % N)
         np.testing.assert_array_equal(r["iters"], ro["iters"], err_msg="6-DOF N=%d" % N)
@@ -32,7 +32,7 @@ def test_every_horizon_matches_the_oracle(oracle):
         e12 = tg.BatchedMPC12(tg.mpc12_params(N=N))
         x12, ref12 = oracle.synth_mpc12(12, N, 0.1, B)
         r12 = e12.solve_host(x12, ref12)
-        oracle.match_rho_classes(e12.rho_rows())
+        oracle.match_engine(e12)
         s = {k: oracle.fixed_rho_settings(e12.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
         ro12 = oracle.mpc12_batch(oracle.mpc12_params(N=N), s, x12, ref12)
         np.testing.assert_array_equal(r12["status"], ro12["status"], err_msg="12-state N=%d" % N)
@@ -54,7 +54,7 @@ def test_horizons_past_50_match_the_oracle_and_the_limit_is_an_error(oracle):
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N))
         x0, ref = oracle.synth_mpc6(11, N, 0.1, B)
         r = eng.solve_host(x0, ref)
-        oracle.match_rho_classes(eng.rho_rows())
+        oracle.match_engine(eng)
         ro = oracle.mpc6_batch(oracle.mpc6_params(N=N), oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
         np.testing.assert_array_equal(r["status"], ro["status"], err_msg="6-DOF N=%d" % N)
         np.testing.assert_array_equal(r["iters"], ro["iters"], err_msg="6-DOF N=%d" % N)
@@ -64,7 +64,7 @@ def test_horizons_past_50_match_the_oracle_and_the_limit_is_an_error(oracle):
         e12 = tg.BatchedMPC12(tg.mpc12_params(N=N))
         x12, ref12 = oracle.synth_mpc12(12, N, 0.1, B)
         r12 = e12.solve_host(x12, ref12)
-        oracle.match_rho_classes(e12.rho_rows())
+        oracle.match_engine(e12)
         s = {k: oracle.fixed_rho_settings(e12.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
         ro12 = oracle.mpc12_batch(oracle.mpc12_params(N=N), s, x12, ref12)
         np.testing.assert_array_equal(r12["status"], ro12["status"], err_msg="12-state N=%d" % N)

@@ -67,7 +67,7 @@ def test_matrices_bit_exact_6dof(tg, oracle, N, smooth):
     w = oracle.Osqp(qp["P"], qp["A"], qp["q"], qp["l"], qp["u"], oracle.fixed_rho_settings(eng1.rho))
     np.testing.assert_array_equal(eng1.get(capi.TG_VEC_RHO), w.rho_vec())
     # built-in multipliers only touch inequality rows and are read back exactly
-    cls = oracle.match_rho_classes(eng.rho_rows())
+    cls = oracle.match_engine(eng)
     same = rho == eng1.get(capi.TG_VEC_RHO)
     Nx = 6 * (N + 1)
     assert same[:Nx].all() and cls == ((15.0, 1.0, 1.0, 3.0) if N <= 30 else (12.0, 3.0, 1.0, 4.0))
@@ -146,7 +146,7 @@ def test_solve_matches_oracle_6dof(tg, oracle, N, B, eps, smooth, scale, fine):
     eng = tg.BatchedMPC6(p, tg.make_opts(eps_abs=eps, eps_rel=eps, rho_scale=scale or (0, 0, 0, 0), check_fine=fine))
     x0, ref = oracle.synth_mpc6(SEED + 2, N, 0.1, B)
     r = eng.solve_host(x0, ref)
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, eps_abs=eps, eps_rel=eps, warm_start=0,
                                                          check_fine=fine), x0, ref)
     assert (r["status"] == 1).all() and (ro["status"] == 1).all()
@@ -162,7 +162,7 @@ def test_solve_matches_oracle_12state(tg, oracle, N, B):
     x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B)
     r = eng.solve_host(x12, ref12)
     s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc12_batch(op, s, x12, ref12)
     np.testing.assert_array_equal(r["status"], ro["status"])
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -187,7 +187,7 @@ def test_solve_matches_oracle_12state_variants(tg, oracle, N, B, smooth, stress)
         x12, ref12 = synth.stress("12state", x12, ref12, N)
     r = eng.solve_host(x12, ref12)
     s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc12_batch(op, s, x12, ref12)
     np.testing.assert_array_equal(r["status"], ro["status"])
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -210,7 +210,7 @@ def test_verdicts_at_max_iter_match_osqp(tg, oracle, N, eps, budget):
     xs, rs = synth.stress("6dof", x0[:B // 3], ref[:B // 3], N)
     x0 = np.concatenate([x0[B // 3:], xs]); ref = np.concatenate([ref[B // 3:], rs])
     r = eng.solve_host(x0, ref)
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, eps_abs=eps, eps_rel=eps, max_iter=budget, warm_start=0), x0, ref)
     np.testing.assert_array_equal(r["status"], ro["status"])
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -229,7 +229,7 @@ def test_solve_matches_oracle_6dof_stress(tg, oracle, N, B):
     x0, ref = oracle.synth_mpc6(SEED + 8, N, 0.1, B)
     x0, ref = synth.stress("6dof", x0, ref, N)
     r = eng.solve_host(x0, ref)
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
     np.testing.assert_array_equal(r["status"], ro["status"])
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -249,7 +249,7 @@ def test_lowrank_operator_form_matches_oracle(tg, oracle, model, N, B, smooth):
         x0, ref = oracle.synth_mpc6(SEED + 9, N, 0.1, B)
         lr = tg.BatchedMPC6(p, tg.make_opts(lowrank=1)); de = tg.BatchedMPC6(p, tg.make_opts(lowrank=-1))
         r, rd = lr.solve_host(x0, ref), de.solve_host(x0, ref)
-        oracle.match_rho_classes(lr.rho_rows())
+        oracle.match_engine(lr)
         ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(lr.rho, warm_start=0), x0, ref)
         ok = r["status"] == 1
     else:
@@ -259,7 +259,7 @@ def test_lowrank_operator_form_matches_oracle(tg, oracle, model, N, B, smooth):
         de = tg.BatchedMPC12(tg.mpc12_params(**kw), tg.make_opts(lowrank=-1))
         r, rd = lr.solve_host(x0, ref), de.solve_host(x0, ref)
         s = {k: oracle.fixed_rho_settings(lr.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
-        oracle.match_rho_classes(lr.rho_rows())
+        oracle.match_engine(lr)
         ro = oracle.mpc12_batch(oracle.mpc12_params(**kw), s, x0, ref)
         ok = (r["status"] == 1).all(1)
     np.testing.assert_array_equal(r["status"], ro["status"])
@@ -427,7 +427,7 @@ def test_warm_start_matches_oracle(tg, oracle):
     a = eng.solve_host(x0, ref, warm=True)
     b = eng.solve_host(x1, ref1, warm=True)
     cold = eng.solve_host(x1, ref1, warm=False)
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     for i in range(B):
         m = oracle.Mpc6(op, oracle.fixed_rho_settings(eng.rho))
         ra = m.loop(x0[i], ref[i]); rb = m.loop(x1[i], ref1[i])
@@ -452,7 +452,7 @@ def test_ragged_empty_and_padding(tg, oracle):
     buf["X"].fill_(-7.0); buf["U"].fill_(-7.0); buf["status"].fill_(99)
     eng.solve(buf)
     torch.cuda.synchronize()
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
     assert np.abs(buf["X"][:, :B].cpu().numpy().T - ro["X"]).max() < 1e-9
     assert (buf["X"][:, B:] == -7.0).all() and (buf["U"][:, B:] == -7.0).all()   # padding untouched
@@ -472,7 +472,7 @@ def test_infeasible_instance_reports_failure(tg, oracle, fine):
     x0[2, 3] = 50.0                                 # |v_x(0)| > v_max: step-0 box contradicts x(0) = x0
     eng = tg.BatchedMPC6(p, tg.make_opts(check_fine=fine))
     r = eng.solve_host(x0, ref)
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0, check_fine=fine), x0, ref)
     assert r["status"][2] == -3 and ro["status"][2] == oracle.PRIMAL_INFEASIBLE
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -494,7 +494,7 @@ def test_12state_failed_stage_gates_the_later_ones(tg, oracle):
     x12, ref12 = oracle.synth_mpc12(SEED + 3, N, 0.1, B, first)
     r = eng.solve_host(x12, ref12)
     s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc12_batch(op, s, x12, ref12)
     np.testing.assert_array_equal(r["status"], ro["status"])
     np.testing.assert_array_equal(r["iters"], ro["iters"])
@@ -526,7 +526,7 @@ def test_slot_refill_is_bit_identical_6dof(tg, oracle, fine, cap):
         assert ok.sum() == B - 1 and a["status"][77] == -3
         assert np.abs(a["X"][ok] - b["X"][ok]).max() == 0.0 and np.abs(a["U"][ok] - b["U"][ok]).max() == 0.0
     assert len(np.unique(res[0][0]["iters"])) > 1     # slots did finish at different times
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     idx = np.arange(300, 333)                         # instances that entered through the queue
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0, check_fine=fine), x0[idx], ref[idx])
     np.testing.assert_array_equal(res[1][0]["iters"][idx], ro["iters"])
@@ -659,7 +659,7 @@ def test_closed_loop_rollout_matches_oracle(tg, oracle, model):
     _to_dev(buf, x0, ref)
     out = closed_loop(eng, buf, steps, warm=True, record=True, stats_every=1)
     assert out["solved_frac"] == [1.0] * steps
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     worst = 0.0
     for b in range(B):
         m = mk()
@@ -683,7 +683,7 @@ def test_horizon_limits_are_reported(tg, oracle):
     eng = tg.BatchedMPC6(p)
     x0, ref = oracle.synth_mpc6(5, N, 0.1, 3)
     r = eng.solve_host(x0, ref)
-    oracle.match_rho_classes(eng.rho_rows())
+    oracle.match_engine(eng)
     ro = oracle.mpc6_batch(op, oracle.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
     np.testing.assert_array_equal(r["iters"], ro["iters"])
     assert np.abs(r["X"] - ro["X"]).max() < 1e-9

@@ -9,7 +9,7 @@ O.build()
 bad = 0
 for fam, N in (("6dof", 20), ("6dof", 50), ("12state", 20)):
     eng = tg.BatchedMPC6(tg.mpc6_params(N=N)) if fam == "6dof" else tg.BatchedMPC12(tg.mpc12_params(N=N))
-    O.match_rho_classes(eng.rho_rows())
+    O.match_engine(eng)
     for B in (1, 2, 15, 16, 17, 31, 255, 4095, 4096, 4097, 4111, 4113, 8191, 20001):
         if fam == "6dof":
             x, ref = O.synth_mpc6(31, N, 0.1, B); r = eng.solve_host(x, ref)

@@ -106,7 +106,7 @@ for trial in range(TRIALS):
             for i in rng.choice(B, size=min(B, 3), replace=False):
                 ax = int(rng.integers(0, 3))
                 x0[i, 3 + ax] = float(rng.choice([-1, 1])) * kw6["max_vel"][ax] * float(rng.uniform(1.05, 3.0))
-        O.match_rho_classes(eng.rho_rows())
+        O.match_engine(eng)
         op = O.mpc6_params(**kw6)
         mark("6dof  trial %3d %s: engine" % (trial, desc))
         r = eng.solve_host(x0, ref)
@@ -238,7 +238,7 @@ for trial in range(TRIALS):
         mark("12st  trial %3d %s: engine" % (trial, desc))
         r = eng.solve_host(x, ref)
         mark("12st  trial %3d engine done (iters max %d), oracle" % (trial, r["iters"].max()))
-        O.match_rho_classes(eng.rho_rows())
+        O.match_engine(eng)
         s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
         ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
         report("12st ", trial, desc, r, ro, (ro["status"] == 1).all(1), 1e-7)

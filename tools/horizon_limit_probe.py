@@ -15,7 +15,7 @@ for N in range(lo, hi + 1):
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N))
         x0, ref = O.synth_mpc6(11, N, 0.1, B)
         r = eng.solve_host(x0, ref)
-        O.match_rho_classes(eng.rho_rows())
+        O.match_engine(eng)
         ro = O.mpc6_batch(O.mpc6_params(N=N), O.fixed_rho_settings(eng.rho, warm_start=0), x0, ref)
         ok = ro["status"] == 1
         e6 = (r["status"] != ro["status"]).sum() + (r["iters"] != ro["iters"]).sum()
@@ -27,7 +27,7 @@ for N in range(lo, hi + 1):
         e12 = tg.BatchedMPC12(tg.mpc12_params(N=N))
         x12, ref12 = O.synth_mpc12(12, N, 0.1, B)
         r12 = e12.solve_host(x12, ref12)
-        O.match_rho_classes(e12.rho_rows())
+        O.match_engine(e12)
         s = dict(xy=O.fixed_rho_settings(e12.rho("xy"), warm_start=0), z=O.fixed_rho_settings(e12.rho("z"), warm_start=0),
                  yaw=O.fixed_rho_settings(e12.rho("yaw"), warm_start=0))
         ro12 = O.mpc12_batch(O.mpc12_params(N=N), s, x12, ref12)

@@ -25,7 +25,7 @@ for trial in range(TRIALS):
         e = tg.BatchedMPC6(tg.mpc6_params(**kw6))
         x0, ref = O.synth_mpc6(100 + trial, N, dt, B)
         r = e.solve_host(x0, ref)
-        O.match_rho_classes(e.rho_rows())
+        O.match_engine(e)
         ro = O.mpc6_batch(O.mpc6_params(**kw6), O.fixed_rho_settings(e.rho, warm_start=0), x0, ref)
         ok = ro["status"] == 1
         mism = int((r["status"] != ro["status"]).sum() + (r["iters"] != ro["iters"]).sum())
@@ -49,7 +49,7 @@ for trial in range(TRIALS):
         e = tg.BatchedMPC12(tg.mpc12_params(**kw12))
         x, ref = O.synth_mpc12(200 + trial, N, dt, B)
         r = e.solve_host(x, ref)
-        O.match_rho_classes(e.rho_rows())
+        O.match_engine(e)
         s = {k: O.fixed_rho_settings(e.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
         ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
         ok = (ro["status"] == 1).all(1)

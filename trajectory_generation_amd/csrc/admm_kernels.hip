@@ -134,6 +134,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // slot's ||q||_inf in red[6]) to keep the iteration loop's registers for the iterates.
     bool exhausted = a.queue == nullptr;    // no further instance to take
     bool done = false;
+    // instances of this launch: the batch, or (later phases of the step-size schedule) as many
+    // entries of a.list as the previous phase handed over
+    const int Beff = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.B;
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
     // Cell cc of thread group g: linear cell index ax * (N+1) + st, or ncell for an unused slot.
@@ -402,9 +405,12 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
 #pragma unroll
                     for (int k = 0; k < S; k++) {
+                        // the rows hold x, z and y itself; the kernel keeps y / rho under its own operator
                         x[cc][k] = a.warm[w0 + (size_t)k * a.ldw];
-                        zb[cc][k] = a.warm[w0 + (size_t)(n_int + k) * a.ldw];   // SM: this row holds s
-                        if constexpr (!SM) yb[cc][k] = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw];
+                        const double zv = a.warm[w0 + (size_t)(n_int + k) * a.ldw];
+                        const double yv = a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] / crho_t(cc, k);
+                        if constexpr (SM) zb[cc][k] = zv + yv;
+                        else { zb[cc][k] = zv; yb[cc][k] = yv; }
                     }
                     const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
 #pragma unroll
@@ -441,7 +447,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                         for (int k = 0; k < 6; k++) {
                             zm[mm][k] = a.warm[m0 + (size_t)k * a.ldw];
-                            ym[mm][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw];
+                            ym[mm][k] = a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw] / P.rho_mx[k];
                         }
                     }
                 }
@@ -457,8 +463,8 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         return qmax;
     };
     {
-        int inst0 = blockIdx.x * kTileDev + t;
-        if (a.list && inst0 < a.B) inst0 = a.list[inst0];
+        const int tk0 = blockIdx.x * kTileDev + t;
+        const int inst0 = tk0 < Beff ? (a.list ? a.list[tk0] : tk0) : a.B;   // a.B: no instance
         double qf = load(true, inst0);
         if (g == 0) { red[6 * 16 + t] = 0ull; slot_inst[t] = inst0; slot_start[t] = 0; }
         __syncthreads();
@@ -1093,7 +1099,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     const bool refill = a.queue != nullptr;
     const int nphase = fine > 0 ? max(check / fine, 1) : 1;
     unsigned phase_mask = 1u;
-    for (int iter = 0;;) {
+    // iterations count from the start of an instance's run: a later phase of the step-size schedule
+    // takes its instances at iteration phase_start (a multiple of check)
+    const int phase_start = P.phase_start, phase_end = P.phase_end;
+    for (int iter = phase_start;;) {
         const int gap = (fine > 0 && iter >= check) ? fine : check;
         const int burst = refill ? gap : min(gap, max_iter - iter);
         for (int i = 1; i < burst; i++) {
@@ -1299,12 +1308,16 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // recession cone of [l, u], separates the constraint set from the range of A
             const bool pinf = sfull && eligible && !(m_rp < eps_p) && eps_pinf > 0.0 && pin_n > kDivisionTol &&
                               pin_l < -eps_pinf * pin_n && m_atdy < eps_pinf * pin_n;
+            // an instance still running at the end of this launch's phase moves on to the next
+            // operator: its iterates go to the warm rows and its number to the next launch's list
+            const bool fin = conv || pinf || last;
+            const bool pexit = !fin && a.next_list != nullptr && local >= phase_end;
             CSTAMP(3);
-            if (!done && (conv || pinf || last)) {
+            if (!done && (fin || pexit)) {
                 done = true;
                 const int inst = slot_inst[t];
                 int verdict = conv ? TG_DEV_SOLVED : (pinf ? TG_DEV_PRIMAL_INFEASIBLE : TG_DEV_MAX_ITER);
-                if (!conv && !pinf) {
+                if (fin && !conv && !pinf) {
                     // max_iter reached: OSQP tests once more with every tolerance times ten and reports
                     // "solved inaccurate" / "primal infeasible inaccurate" if that passes (osqp_solve's
                     // last step; osqp-eigen's solve() returns false for these as for max_iter)
@@ -1318,7 +1331,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 // solution out (extractSolution, mpc_6dof.cpp:653; 12-state :1456-1551): for solved
                 // instances only -- mpcLoop returns before extractSolution when solve() is false, so a
                 // failed instance keeps the trajectories of its last successful solve
-                const bool wr = verdict == TG_DEV_SOLVED;
+                const bool wr = fin && verdict == TG_DEV_SOLVED;
 #pragma unroll
                 for (int cc = 0; cc < MAXC; cc++) {
                     const int c = cell_q(cc);
@@ -1333,12 +1346,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         if (st < N) a.U[(size_t)(st * P.U_stride + uoff) * a.ld + inst] = vx[i_var[cc] + D * 16];
                     }
                 }
-                if (g == 0) {
+                if (g == 0 && fin) {
                     if (a.status) a.status[inst] = verdict;
                     if (a.iters) a.iters[inst] = local;
                     if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.res_ld + inst] = m_rd; }
                 }
-                if (a.warm_out) {
+                if (g == 0 && pexit) a.next_list[atomicAdd(a.next_count, 1)] = inst;
+                if (a.warm_out || pexit) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
                         const int c = cell_q(cc);
@@ -1350,9 +1364,15 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             const size_t w0 = (size_t)(abase + st * S) * a.ldw + inst;
 #pragma unroll
                             for (int k = 0; k < S; k++) {
+                                double lo = 0.0, hi = 0.0, zv, yv;
+                                if constexpr (SM) {
+                                    if (CAX || REGC) box_of(cc, k, lo, hi);
+                                    else { lo = lds[i_ct[cc] + k * 3 + 1]; hi = lds[i_ct[cc] + k * 3 + 2]; }
+                                }
+                                zy_of(cc, k, lo, hi, zv, yv);
                                 a.warm[w0 + (size_t)k * a.ldw] = vx[i_var[cc] + k * 16];
-                                a.warm[w0 + (size_t)(n_int + k) * a.ldw] = zb[cc][k];   // SM: s
-                                if constexpr (!SM) a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] = yb[cc][k];
+                                a.warm[w0 + (size_t)(n_int + k) * a.ldw] = zv;
+                                a.warm[w0 + (size_t)(2 * n_int + k) * a.ldw] = crho_t(cc, k) * yv;   // y itself: the same under every operator
                             }
                             const size_t e0 = (size_t)(3 * n_int + c * D) * a.ldw + inst;
 #pragma unroll
@@ -1371,7 +1391,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                             for (int k = 0; k < 6; k++) {
                                 a.warm[m0 + (size_t)k * a.ldw] = zm[mm][k];
-                                a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw] = ym[mm][k];
+                                a.warm[m0 + (size_t)(N1 * 6 + k) * a.ldw] = P.rho_mx[k] * ym[mm][k];
                             }
                         }
                     }
@@ -1423,7 +1443,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     base = __shfl(base, 0);
                     if (need && g == 0) {
                         const int ni = a.queue_base + base + (int)__popcll(mask & ((1ull << t) - 1ull));
-                        next[t] = ni < a.B ? (a.list ? a.list[ni] : ni) : -1;
+                        next[t] = ni < Beff ? (a.list ? a.list[ni] : ni) : -1;
                         red[6 * 16 + t] = 0ull;
                     }
                 }
@@ -1436,10 +1456,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 double qf = load(fresh, ni);
                 qf = wave_gmax(qf);
                 if (fresh && (lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
-                if (fresh && g == 0) { slot_inst[t] = ni; slot_start[t] = iter; }
+                if (fresh && g == 0) { slot_inst[t] = ni; slot_start[t] = iter - phase_start; }
                 if (fine > 0) {
                     // bitwise OR over the live slots (__syncthreads_or only tells whether any bit is set)
-                    const int st0 = fresh ? iter : slot_start[t];
+                    const int st0 = fresh ? iter - phase_start : slot_start[t];
                     if (g == 0 && !done) atomicOr((unsigned *)&next[16], 1u << ((st0 / fine) % nphase));
                     __syncthreads();
                     phase_mask = (unsigned)next[16];
@@ -1809,7 +1829,9 @@ static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream
     BatchArgs b = a;
     b.queue = nullptr;
     b.queue_base = 0;
-    b.list = nullptr;
+    // a.list from the caller: the instances a previous phase of the step-size schedule handed over
+    // (a.count of them); such a launch takes them in that order
+    if (a.count == nullptr) b.list = nullptr;
     // A grid no larger than what the device holds at once, its slots refilled from a queue, keeps
     // every slot busy until the batch runs out; a tile per workgroup makes each tile wait for its
     // slowest instance.  The kernel's slot schedule needs the checks aligned (see admm_kernel).
@@ -1837,7 +1859,7 @@ static hipError_t launch_admm_t(const StageDev &P, const BatchArgs &a, hipStream
             b.queue_base = grid * kTileDev;
             e = hipMemsetAsync(a.queue_mem, 0, sizeof(int), s);
             if (e != hipSuccess) return e;
-            if (a.order_list && a.order_score && a.order_hdr) {
+            if (a.count == nullptr && a.order_list && a.order_score && a.order_hdr) {
                 e = launch_order(P, a, s);
                 if (e != hipSuccess) return e;
                 b.list = a.order_list;

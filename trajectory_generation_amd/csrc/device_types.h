@@ -74,6 +74,11 @@ struct StageDev {
     int U_stride, U_off[kMaxAxes];
     double sigma, alpha, eps_abs, eps_rel, eps_prim_inf;
     int max_iter, check, check_fine;
+    // Step-size schedule: a solve is a sequence of launches, one per operator (phase).  This launch
+    // takes its instances at iteration phase_start of their run (0: fresh problems; > 0: iterates
+    // carried over from the previous phase) and hands those still running at the first check at or
+    // after iteration phase_end to the next phase (BatchArgs::next_list); INT_MAX: the last phase.
+    int phase_start, phase_end;
 };
 
 // reference-ordered tables for the assembly kernel
@@ -108,6 +113,14 @@ struct BatchArgs {
     int *order_list;
     double *order_score;
     unsigned long long *order_hdr;
+    // Phases of the step-size schedule.  count (device, may be null): number of entries of `list`
+    // that make up this launch's batch, in place of B (the previous phase's hand-over count).
+    // next_list / next_count (device, may be null): where this launch appends the instances it
+    // hands over to the next phase; their iterates go to `warm` (x, z, y with y unscaled, so that
+    // the rows mean the same under every operator).
+    const int *count;
+    int *next_list;
+    int *next_count;
 };
 
 // dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static share (the block-wide vote helpers keep a few words there)

@@ -3,8 +3,10 @@
 // MPC12STATE::mpcLoop (mpc_12state.cpp:1374-1453).
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -96,44 +98,42 @@ struct DevStage {
     double *d_warm = nullptr; int warm_cap = 0; bool warm_valid = false; int warm_B = 0;
     double *d_res = nullptr; int res_cap = 0, res_B = 0;
 
-    // The automatic per-class step sizes are chosen for OSQP's default tolerance, where most
-    // instances pass the first check.  Run tight (eps <= 1e-6: what it takes to land within 1e-4 of
-    // the optimum), the long 6-DOF horizons converge several times faster with a much larger step
-    // on the position rows (the altitude floor) and a smaller one on the inputs: at N = 50 and eps
-    // 1e-9 the mean falls from 1 370 to 360 iterations and the slowest of 4096 instances from 37 000
-    // to 4 700, alike at N = 31 ... 60 and from 1e-6 down, while at 1e-3 the same scales would
-    // double the mean; the short horizons (N = 20: 75 iterations at 1e-9) gain nothing
-    // (tools/tight_rho_sweep.py, held-out seeds).  Chosen at create from the tolerances
-    // given there, like everything that enters the operators; entries the caller sets are kept.
-    static void tolerance_scales(const StageModel &mdl, const tg_solver_opts &o, double scale[4])
-    {
-        for (int k = 0; k < 4; k++) scale[k] = o.rho_scale[k];
-        const double eps = o.eps_abs > o.eps_rel ? o.eps_abs : o.eps_rel;
-        if (!(eps > 0)) return;
-        if (mdl.family == TG_FAM_YAW) {
-            // 12-state chain at eps <= 1e-6: a tenfold step on the yaw-rate rows takes the yaw stage at
-            // N = 20 from 1 090 to 330 iterations in the mean (1e-8: 2 750 to 570) and its slowest
-            // instance from 13 900 to 1 400, alike at N = 30; at N = 40 the mean stays and the slowest
-            // falls as much; the shorter horizons (N = 15: 110 iterations, N = 10: 75) would lose, and the
-            // Z and XY stages are best left
-            if (eps > 1e-6 || mdl.N < 20) return;
-            const double t12[4] = {1.0, 100.0, 3.0, 1.0};
-            for (int k = 0; k < 4; k++) if (!(scale[k] > 0)) scale[k] = t12[k];
-            return;
-        }
-        if (mdl.family != TG_FAM_6DOF || mdl.N <= 30 || eps > 1e-5) return;
-        // in between (eps 1e-5) half that step on the position rows: mean 89 against 114 iterations
-        const double tight[4] = {eps <= 1e-6 ? 96.0 : 48.0, 3.0, 1.0, 2.0};
-        for (int k = 0; k < 4; k++) if (!(scale[k] > 0)) scale[k] = tight[k];
-    }
+    // Step-size schedule (tg_solver_opts::phase_iters / phase_scale): the operators of the phases
+    // after the first (each a stage of its own of which only the operator data is used), and the
+    // iteration counts at which an instance still running moves on.  The lists of instances a phase
+    // hands over (two, used in turn) and their counters are the stage's own device memory.
+    std::vector<std::unique_ptr<DevStage>> later;
+    int phase_iters[2] = {-1, -1};
+    double phase_scale[2][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}};
+    int *d_plist[2] = {nullptr, nullptr}; int plist_cap = 0; int *d_pcount = nullptr;
 
     int init(const StageModel &mdl, const tg_solver_opts &o, double rho)
     {
         std::string err;
-        double scale[4];
-        tolerance_scales(mdl, o, scale);
-        if (!build_stage(mdl, rho, o.sigma, scale, sp, err)) return fail(TG_E_NUMERIC, err);
+        if (!build_stage(mdl, rho, o.sigma, o.rho_scale, sp, err)) return fail(TG_E_NUMERIC, err);
         int rc;
+        // later phases of the step-size schedule: the same stage with the class multipliers of the
+        // phase (relative to this one's), built by a recursive call with the schedule switched off
+        {
+            int it[2]; double sc[2][4];
+            default_phases(mdl, it, sc);
+            for (int p = 0; p < 2; p++) {
+                if (o.phase_iters[p] != 0) it[p] = o.phase_iters[p];
+                for (int k = 0; k < 4; k++) if (o.phase_scale[p][k] > 0) sc[p][k] = o.phase_scale[p][k];
+            }
+            if (it[0] <= 0) it[1] = -1;                          // no second phase, no third
+            if (it[1] > 0 && it[1] <= it[0]) return fail(TG_E_ARG, "phase_iters must increase");
+            for (int p = 0; p < 2; p++) {
+                phase_iters[p] = it[p] > 0 ? it[p] : -1;
+                for (int k = 0; k < 4; k++) phase_scale[p][k] = sc[p][k];
+                if (it[p] <= 0) continue;
+                tg_solver_opts op = o;
+                op.phase_iters[0] = op.phase_iters[1] = -1;
+                for (int k = 0; k < 4; k++) op.rho_scale[k] = sp.rho_scale[k] * sc[p][k];
+                later.emplace_back(new DevStage());
+                if ((rc = later.back()->init(mdl, op, rho))) return rc;
+            }
+        }
         if ((rc = upload(sp.Mfrag, &d_Mfrag))) return rc;
         HIP_TRY(hipMalloc((void **)&d_queue, sizeof(int)));
         grid_cap = o.grid_cap;
@@ -397,6 +397,9 @@ struct DevStage {
     }
     void release()
     {
+        for (auto &l : later) l->release();
+        later.clear();
+        hipFree(d_plist[0]); hipFree(d_plist[1]); hipFree(d_pcount);
         hipFree(d_Mfrag); hipFree(d_DUfrag); hipFree(d_Wfrag); hipFree(d_queue);
         hipFree(d_qw); hipFree(d_lt); hipFree(d_ut); hipFree(d_qrr); hipFree(d_x0r); hipFree(d_ovb);
         hipFree(d_ovm); hipFree(d_warm); hipFree(d_res);
@@ -442,6 +445,18 @@ struct DevStage {
         order_cap = cap;
         return TG_OK;
     }
+    // hand-over lists of the step-size schedule: two lists of instance numbers and a counter per phase boundary
+    int ensure_plist(int B)
+    {
+        if (!d_pcount) HIP_TRY(hipMalloc((void **)&d_pcount, 2 * sizeof(int)));
+        if (B <= plist_cap) return TG_OK;
+        hipFree(d_plist[0]); hipFree(d_plist[1]); d_plist[0] = d_plist[1] = nullptr; plist_cap = 0;
+        const int cap = (B + 255) / 256 * 256;
+        HIP_TRY(hipMalloc((void **)&d_plist[0], (size_t)cap * sizeof(int)));
+        HIP_TRY(hipMalloc((void **)&d_plist[1], (size_t)cap * sizeof(int)));
+        plist_cap = cap;
+        return TG_OK;
+    }
     // primal / dual residual of every instance at its exit, [2][res_cap]
     int ensure_res(int ld)
     {
@@ -480,6 +495,24 @@ struct DevStage {
             a.order_list = d_olist; a.order_score = d_oscore; a.order_hdr = d_ohdr;
         }
         a.grid_cap = grid_cap;
+        a.count = nullptr; a.next_list = nullptr; a.next_count = nullptr;
+        // The step-size schedule: phase p ends at the first check at or after phase_iters[p]; an
+        // end at or beyond max_iter never comes.  Without allocation there is one phase only.
+        int bound[2] = {0, 0}, nphase = 1;
+        if (!no_alloc) {
+            for (int p = 0; p < (int)later.size(); p++) {
+                const int b = (phase_iters[p] + dev.check - 1) / dev.check * dev.check;
+                if (b >= dev.max_iter || (p > 0 && b <= bound[p - 1])) break;
+                bound[p] = b; nphase = p + 2;
+            }
+        }
+        if (nphase > 1) {
+            int rc = ensure_warm(a.B, s);         // the hand-over travels through the warm rows
+            if (rc) return rc;
+            if ((rc = ensure_plist(a.B))) return rc;
+            a.ldw = warm_cap; a.warm = d_warm;
+            HIP_TRY(hipMemsetAsync(d_pcount, 0, 2 * sizeof(int), s));
+        }
         const char *why = "";
         hipEvent_t e0 = nullptr, e1 = nullptr;
         bool timing = false;
@@ -494,21 +527,36 @@ struct DevStage {
                 return fail(TG_E_HIP, "timing events could not be created");
             }
         }
-        hipError_t e = launch_admm(dev, a, s, &why);
-        if (e != hipSuccess) {
-            if (timing) { hipEventDestroy(e0); hipEventDestroy(e1); }
-            return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
-                        std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
+        for (int p = 0; p < nphase; p++) {
+            StageDev d = p == 0 ? dev : later[p - 1]->dev;
+            if (p > 0) {   // the run-time settings are those of the stage
+                d.alpha = dev.alpha; d.eps_abs = dev.eps_abs; d.eps_rel = dev.eps_rel; d.eps_prim_inf = dev.eps_prim_inf;
+                d.max_iter = dev.max_iter; d.check = dev.check; d.check_fine = dev.check_fine;
+            }
+            d.phase_start = p > 0 ? bound[p - 1] : 0;
+            d.phase_end = p + 1 < nphase ? bound[p] : INT_MAX;
+            BatchArgs ap = a;
+            if (p > 0) {
+                ap.count = d_pcount + (p - 1); ap.list = d_plist[(p - 1) & 1]; ap.warm_in = 1;
+                ap.order_list = nullptr; ap.order_score = nullptr; ap.order_hdr = nullptr;
+            }
+            if (p + 1 < nphase) { ap.next_list = d_plist[p & 1]; ap.next_count = d_pcount + p; }
+            hipError_t e = launch_admm(d, ap, s, &why);
+            if (e != hipSuccess) {
+                if (timing) { hipEventDestroy(e0); hipEventDestroy(e1); }
+                return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
+                            std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
+            }
         }
         if (timing) {
             if (hipEventRecord(e1, s) != hipSuccess) {
                 hipEventDestroy(e0); hipEventDestroy(e1);
                 return fail(TG_E_HIP, "timing event could not be recorded");
             }
-            int d = 0;
-            hipGetDevice(&d);
+            int dv = 0;
+            hipGetDevice(&dv);
             std::lock_guard<std::mutex> lk(g_time_mu);
-            g_pending.push_back({e0, e1, d});
+            g_pending.push_back({e0, e1, dv});
         }
         if (warm) { warm_valid = true; warm_B = a.B; }
         res_B = no_alloc ? 0 : a.B;   // a solve without a residual record leaves none of an earlier one behind
@@ -533,6 +581,10 @@ struct DevStage {
         out->max_iter = dev.max_iter; out->check_termination = dev.check; out->check_fine = dev.check_fine;
         out->grid_cap = grid_cap; out->hard_first = hard_first; out->lowrank = dev.lr;
         for (int k = 0; k < 4; k++) out->rho_scale[k] = sp.rho_scale[k];
+        for (int p = 0; p < 2; p++) {
+            out->phase_iters[p] = phase_iters[p];
+            for (int k = 0; k < 4; k++) out->phase_scale[p][k] = phase_scale[p][k];
+        }
     }
     // options that do not enter the factorised operator can change on a live handle
     void set_run_opts(const tg_solver_opts &o)
@@ -602,6 +654,9 @@ static int check_opts(const tg_solver_opts &o)
         return fail(TG_E_ARG, "invalid solver options");
     for (int k = 0; k < 4; k++)
         if (!(o.rho_scale[k] >= 0)) return fail(TG_E_ARG, "rho_scale entries must be >= 0");
+    for (int p = 0; p < 2; p++)
+        for (int k = 0; k < 4; k++)
+            if (!(o.phase_scale[p][k] >= 0)) return fail(TG_E_ARG, "phase_scale entries must be >= 0");
     return TG_OK;
 }
 
@@ -612,6 +667,10 @@ void tg_default_opts(tg_solver_opts *o)
     o->rho = 0.0; o->sigma = 1e-6; o->alpha = 1.6; o->eps_abs = 1e-3; o->eps_rel = 1e-3;
     o->max_iter = 4000; o->check_termination = 25; o->eps_prim_inf = 1e-4; o->check_fine = 0; o->grid_cap = 0; o->lowrank = 0; o->hard_first = 0;
     for (int k = 0; k < 4; k++) o->rho_scale[k] = 0.0;
+    for (int p = 0; p < 2; p++) {
+        o->phase_iters[p] = 0;
+        for (int k = 0; k < 4; k++) o->phase_scale[p][k] = 0.0;
+    }
 }
 const char *tg_last_error(void) { return g_err.c_str(); }
 int tg_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }

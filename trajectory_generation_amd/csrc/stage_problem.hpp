@@ -197,6 +197,29 @@ inline void default_rho_scale(const StageModel &mdl, double out[4])
     else { out[0] = 1.0; out[1] = 10.0; out[2] = 3.0; out[3] = 3.0; }   // slowest XY / yaw instance 2466 / 297 -> 109 / 94
 }
 
+// Built-in step-size schedule: iteration counts at which an instance that is still running moves
+// to the next operator, and that operator's class multipliers relative to the first one's.
+// iters[p] <= 0: no such phase.
+// The class multipliers above are tuned for the bulk of the instances, which pass OSQP's default
+// tolerance at the first or second check.  The instances that take long, and everything run to
+// a tight tolerance, are held up by the altitude floor rows of the 6-DOF model: their iteration
+// count falls in proportion to a larger step there, which in turn would slow the bulk down.  So
+// the step on those rows grows only for instances still running after 100 and 200 iterations
+// (x 8, x 64).  N = 50, 16384 seeded instances: at eps 3e-9 mean 132 / slowest 1200 iterations
+// against 324 / 4775 with the best single operator; at eps 1e-3 the mean stays 26.8 and the
+// slowest instance needs 125 instead of 300 (tools/rho_policy_probe.py).
+inline void default_phases(const StageModel &mdl, int iters[2], double scale[2][4])
+{
+    for (int p = 0; p < 2; p++) {
+        iters[p] = -1;
+        for (int k = 0; k < 4; k++) scale[p][k] = 1.0;
+    }
+    if (mdl.family == TG_FAM_6DOF) {
+        iters[0] = 100; scale[0][0] = 8.0;
+        iters[1] = 200; scale[1][0] = 64.0;
+    }
+}
+
 inline bool build_stage(const StageModel &mdl, double rho, double sigma, const double rho_scale_in[4],
                         StageProblem &sp, std::string &err)
 {

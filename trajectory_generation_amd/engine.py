@@ -16,7 +16,8 @@ def _torch():
 
 
 def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000,
-              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0, grid_cap=0, lowrank=0, hard_first=0):
+              check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0, grid_cap=0, lowrank=0, hard_first=0,
+              phase_iters=(0, 0), phase_scale=((0.0,) * 4, (0.0,) * 4)):
     """rho <= 0 and rho_scale entries of 0 select the engine's built-in choices; rho_scale is
     (position, velocity, acceleration, input) multipliers of rho on the box rows;
     eps_prim_inf = 0 switches the primal infeasibility test off; check_fine > 0: after the first
@@ -24,7 +25,10 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
     grid_cap: most workgroups a solve launches (0: what the GPU holds at once, < 0: one per tile of
     16 instances); a smaller grid refills its instance slots from the rest of the batch;
     lowrank: K^-1 as diagonal tiles + low-rank rest (0: where it pays, 1: wherever possible, -1: dense).
-    hard_first: a refilled grid takes the likely slow instances first (0; -1: batch order)."""
+    hard_first: a refilled grid takes the likely slow instances first (0; -1: batch order).
+    phase_iters / phase_scale: the step-size schedule -- an instance still running at the first check
+    at or after phase_iters[p] continues under an operator whose class multipliers are rho_scale x
+    phase_scale[p] (0: built-in choice, phase_iters < 0: no such phase)."""
     o = capi.SolverOpts()
     capi.load().tg_default_opts(C.byref(o))
     o.rho_scale[:] = [float(v) for v in rho_scale]
@@ -35,6 +39,10 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
     o.grid_cap = grid_cap
     o.lowrank = lowrank
     o.hard_first = hard_first
+    for p in range(2):
+        o.phase_iters[p] = int(phase_iters[p])
+        for k in range(4):
+            o.phase_scale[p][k] = float(phase_scale[p][k])
     return o
 
 
