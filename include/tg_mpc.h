@@ -120,8 +120,9 @@ typedef struct {
      * (x, z, y) carried over -- any rho is a valid ADMM step, which is what OSQP's own adaptation
      * relies on.  Decided per instance, at the check; instances that move are gathered and solved
      * together, so the operator stays shared.  phase_scale[p] multiplies the first operator's
-     * rho_scale for phase p + 1.  phase_iters: 0 = the built-in choice (6-DOF: 100 and 200 with
-     * the step on the position rows x 8 and x 64; 12-state stages: see tg_mpc12_get_opts),
+     * rho_scale for phase p + 1.  phase_iters: 0 = the built-in choice (100 and 200 iterations;
+     * 6-DOF: the step on the position rows x 8 and x 64, 12-state Z and yaw stages: on the speed
+     * rows x 10 and x 100, XY stage: on the acceleration rows x 3 and x 10),
      * < 0 = no such phase; phase_scale entries of 0 = built-in.  Frozen at create (the operators
      * are built there); tg_*_set_opts ignores both.  The entry point that allocates nothing runs
      * the first operator only. */
@@ -225,8 +226,11 @@ int tg_mpc12_solve_host(tg_mpc12 *h, int B, const double *x0, const double *ref,
 
 /* No counterpart in the reference: tg_mpc12_solve_batch for callers that cannot allocate device
  * memory at call time -- code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  Same three stages, same kernels and bit-identical X / U / status / iters (cold start
- * only: there is no warm argument, no residual record and no kernel timing), but the arrays that
+ * hipMalloc.  Same three stages, same kernels and bit-identical X / U / status / iters on a handle
+ * whose step-size schedule is off (phase_iters = {-1, -1}; with a schedule this entry point runs
+ * every instance under the first operator to the end, since the hand-over between operators needs
+ * per-instance storage it has no room for).  Cold start only: there is no warm argument, no
+ * residual record and no kernel timing.  The arrays that
  * pass between the stages (xy_max, mixed_max, yaw_ref), the stages' solutions until all three have
  * solved, the stage status rows when d_status is NULL and the kernels' queue counters live in a
  * static device array of 32 MiB that every GPU the library runs on holds until the process ends,

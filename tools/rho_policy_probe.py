@@ -42,10 +42,50 @@ def problem(model, N, B, seed_off, first=0, stage=None):
                 cls[Nx + 6 * i + a] = 0 if a < 3 else 1
         cls[2 * Nx:] = 3
         return P, A, q, l, u, cls
-    raise SystemExit("only 6dof here")
+    # one stage of the 12-state chain; the upstream solutions come from the oracle's own chain run tight
+    fam = {"xy": O.FAM_XY, "z": O.FAM_Z, "yaw": O.FAM_YAW}[stage]
+    p = O.mpc12_params(N=N)
+    d = O.build_qp(p, fam)
+    P, A = d["P"], d["A"]
+    n, m, nx, nu = d["n"], d["m"], d["nx"], d["nu"]
+    x12, ref12 = O.synth_mpc12(SEED + seed_off, N, 0.1, B, first)
+    O.set_rho_class_scale(1.0, 10.0, 3.0, 3.0)
+    tight = {k: O.fixed_rho_settings(r, warm_start=0, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+             for k, r in (("xy", 500.0), ("z", 500.0), ("yaw", 200.0))}
+    chain = O.Mpc12(p, tight)
+    q = np.zeros((B, n)); l = np.zeros((B, m)); u = np.zeros((B, m))
+    keep = []
+    for b in range(B):
+        r = chain.loop(x12[b], ref12[b])
+        xyref, zref, yawref = O.split_ref12(N, ref12[b])
+        x = x12[b]
+        if stage == "z":
+            q[b], l[b], u[b] = O.qp12_vectors(p, fam, x[6:9], zref)
+        elif stage == "xy":
+            if r["status"][0] != 1:
+                continue
+            q[b], l[b], u[b] = O.qp12_vectors(p, fam, x[0:6], xyref, r["xy_max"], r["mixed_max"])
+        else:
+            if not r["ok"]:
+                continue
+            q[b], l[b], u[b] = O.qp12_vectors(p, fam, x[9:12], r["yaw_ref"])
+        keep.append(b)
+    O.set_rho_class_scale(1.0, 1.0, 1.0, 1.0)
+    keep = np.array(keep)
+    q, l, u = q[keep], l[keep], u[keep]
+    cls = np.full(m, -1)
+    Nx, Nu = nx * (N + 1), nu * N
+    for i in range(N + 1):
+        for a in range(nx):
+            cls[Nx + nx * i + a] = a % 3
+    cls[2 * Nx:2 * Nx + Nu] = 3
+    for r_ in range(2 * Nx + Nu, m):
+        cls[r_] = 1 if (r_ - 2 * Nx - Nu) % 6 < 4 else 2
+    return P, A, q, l, u, cls
 
 
 def rho_vector(l0, u0, cls, rho, scale):
+    """(the engine types the rows from the init-time bounds: x0 = 0, widest boxes)"""
     m = len(l0)
     r = np.full(m, rho)
     eq = (u0 - l0) < 1e-4
@@ -126,15 +166,24 @@ def main():
     ap.add_argument("--B", type=int, default=4096)
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--seed-off", type=int, default=4)
-    ap.add_argument("--eps", type=float, default=3e-9)
+    ap.add_argument("--eps", default="3e-9", help="tolerance, or a comma-separated list of them")
     ap.add_argument("--max-iter", type=int, default=8000)
     ap.add_argument("--rho", type=float, default=1000.0)
     ap.add_argument("--set", default="a")
+    ap.add_argument("--stage", default=None, help="12state: z, xy or yaw")
+    ap.add_argument("--base", default=None, help="class multipliers of the first operator, e.g. 1,10,3,3")
+    ap.add_argument("--grid", default=None,
+                    help="set 'g': semicolon-separated schedules, each 'k1:p,v,a,i[/k2:p,v,a,i]' with multipliers relative to --base")
     args = ap.parse_args()
     dev = "cuda" if torch.cuda.is_available() else "cpu"
-    P, A, q, l, u, cls = problem(args.model, args.N, args.B, args.seed_off, args.first)
-    l0, u0 = l[0].copy(), u[0].copy()
-    l0[:6] = 0; u0[:6] = 0
+    P, A, q, l, u, cls = problem(args.model, args.N, args.B, args.seed_off, args.first, args.stage)
+    from oracle import oracle as O
+    if args.model == "6dof":
+        d0 = O.build_qp(O.mpc6_params(N=args.N))
+    else:
+        d0 = O.build_qp(O.mpc12_params(N=args.N), {"xy": O.FAM_XY, "z": O.FAM_Z, "yaw": O.FAM_YAW}[args.stage])
+    l0, u0 = d0["l"], d0["u"]
+    print("instances %d, n %d, m %d" % (q.shape[0], q.shape[1], l.shape[1]), flush=True)
     rv = lambda mult, scale: rho_vector(l0, u0, cls, args.rho * mult, scale)
     stay = lambda it, op, rp, rd: op
     policies = {}
@@ -211,12 +260,34 @@ def main():
                                        (12.0, 75, 96.0, 250, 800.0), (12.0, 100, 100.0, 200, 800.0)):
             policies["(pos %g, vel 3, inp 4) -> pos %g after %d -> pos %g after %d" % (pos0, p1, k1, p2, k2)] = (
                 [rv(1, (pos0, 3.0, 1.0, 4.0)), rv(1, (p1, 3.0, 1.0, 4.0)), rv(1, (p2, 3.0, 1.0, 4.0))], sched_rule([k1, k2]), 0)
-    for name, (menu, rule, start) in policies.items():
-        t0 = time.time()
-        it, sw, _ = run(dev, P, A, q, l, u, menu, rule, args.eps, args.max_iter, start_op=start)
-        print("%-62s mean %7.1f  p50 %5d  p99 %6d  max %6d  unsolved %d  switches mean %.2f  (%.0f s)"
-              % (name, it.mean(), np.median(it), np.percentile(it, 99), it.max(), int((it >= args.max_iter).sum()), sw.mean(), time.time() - t0),
-              flush=True)
+    if args.set == "g":
+        def sched_rule(bounds):
+            def r(it, op, rp, rd):
+                tgt = sum(1 for b in bounds if it >= b)
+                return torch.maximum(op, torch.full_like(op, tgt))
+            return r
+        base = tuple(float(v) for v in args.base.split(","))
+        policies["fixed %s" % (base,)] = ([rv(1, base)], stay, 0)
+        for spec in args.grid.split(";"):
+            spec = spec.strip()
+            if not spec:
+                continue
+            bounds, menu = [], [rv(1, base)]
+            for ph in spec.split("/"):
+                k, mult = ph.split(":")
+                mult = [float(v) for v in mult.split(",")]
+                bounds.append(int(k))
+                menu.append(rv(1, tuple(b * m_ for b, m_ in zip(base, mult))))
+            policies["%s -> %s" % (base, spec)] = (menu, sched_rule(bounds), 0)
+    for eps in [float(v) for v in str(args.eps).split(",")]:
+        print("eps %g" % eps, flush=True)
+        for name, (menu, rule, start) in policies.items():
+            t0 = time.time()
+            it, sw, _ = run(dev, P, A, q, l, u, menu, rule, eps, args.max_iter, start_op=start)
+            done = it[it < args.max_iter]
+            print("%-62s mean %7.1f  p50 %5d  p99 %6d  max %6d (solved: %6d)  unsolved %d  switches mean %.2f  (%.0f s)"
+                  % (name, it.mean(), np.median(it), np.percentile(it, 99), it.max(), done.max() if len(done) else 0,
+                     int((it >= args.max_iter).sum()), sw.mean(), time.time() - t0), flush=True)
 
 
 if __name__ == "__main__":
