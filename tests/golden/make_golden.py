@@ -116,3 +116,11 @@ def harness():
 if __name__ == "__main__":
     # python tests/golden/make_golden.py [harness] [6dof_N50] [12state_N20] ...  (no argument: everything)
     main(set(sys.argv[1:]))
+
+
+# ---------------------------------------------------------------------------------------------
+# fuzz205_wild_trial{33,41,56}.npz are not made by this script: they are three draws of the
+# differential fuzzer (FUZZ_WILD=1 FUZZ_NO_SCHEDULE=1 FUZZ_DUMP=dir FUZZ_DUMP_TRIALS=33,41,56
+# python tools/fuzz_vs_oracle.py 205 60, on a GPU box) in which the yaw columns of engine and oracle
+# parted by 2e-4 ... 0.4 rad, cut down to the instances that differed most, a few that agreed and
+# a few that failed: inputs (x, ref), model parameters and solver options as JSON text -- no outputs.

@@ -15,7 +15,9 @@ O.build()
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 TRIALS = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 rng = np.random.default_rng(SEED)
+rng_sched = np.random.default_rng(SEED + 7777)   # step-size schedules from a stream of their own: the other draws of a seed stay what they were
 bad = 0
+DUMP = os.environ.get("FUZZ_DUMP")               # directory: inputs, parameters and options of every 12-state trial run (with FUZZ_ONLY)
 WILD = bool(os.environ.get("FUZZ_WILD"))      # parameters far outside the usual ranges
 PROGRESS = bool(os.environ.get("FUZZ_PROGRESS"))   # a line before every engine / oracle call: a stall names its place
 ONLY = [int(v) for v in os.environ.get("FUZZ_ONLY", "").split(",") if v]     # run only these trials (all are drawn)
@@ -40,6 +42,17 @@ def draw_opts(N):
     e["lowrank"] = int(rng.choice([0, 0, 1, -1]))
     e["grid_cap"] = int(rng.choice([0, 0, -1, 1, 2, 3]))
     e["hard_first"] = int(rng.choice([0, -1]))
+    # step-size schedule: the built-in one, none, or a drawn one (boundaries anywhere, not only on the check grid)
+    kind = int(rng_sched.integers(0, 4))
+    if os.environ.get("FUZZ_NO_SCHEDULE"):
+        kind = 1
+    if kind == 1:
+        e["phase_iters"] = (-1, -1)
+    elif kind >= 2:
+        k1 = int(rng_sched.integers(1, 8)) * int(rng_sched.choice([5, 10, 25, 33]))
+        k2 = k1 + int(rng_sched.integers(1, 8)) * int(rng_sched.choice([5, 10, 25, 40])) if kind == 3 else -1
+        e["phase_iters"] = (k1, k2)
+        e["phase_scale"] = tuple(tuple(float(v) for v in 10 ** rng_sched.uniform(-0.5, 1.5, 4)) for _ in range(2))
     import json
     e.update(json.loads(os.environ.get("FUZZ_ENGINE_ONLY", "{}")))      # overrides for bisecting a finding
     for k, v in json.loads(os.environ.get("FUZZ_BOTH", "{}")).items():
@@ -62,8 +75,9 @@ def report(tag, trial, desc, r, ro, solved, tol):
             print("      at %s: engine %d after %d, oracle %d after %d" % (ix, r["status"][ix], r["iters"][ix], ro["status"][ix], ro["iters"][ix]))
         if r["X"].shape[1] % 12 == 0 and r["status"].ndim == 2 and solved.any():
             # 12-state chain: where the trajectories part (columns x, y | z | yaw of every step).  The yaw
-            # reference is atan2 of the planned XY velocities: where those are next to zero it amplifies
-            # rounding-level differences of the XY solution
+            # reference is atan2 of (target - planned position) in y and x (mpc_12state.cpp:544-548): where
+            # that vector is next to zero, or points along the +-pi cut, it amplifies rounding-level
+            # differences of the XY solution
             dX = np.abs(r["X"][solved] - ro["X"][solved]).reshape(int(solved.sum()), -1, 12)
             print("      max-abs difference of the solved instances: xy %.1e  z %.1e  yaw %.1e" % (
                 dX[:, :, :6].max(), dX[:, :, 6:9].max(), dX[:, :, 9:].max()), flush=True)
@@ -242,6 +256,13 @@ for trial in range(TRIALS):
         s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
         ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
         report("12st ", trial, desc, r, ro, (ro["status"] == 1).all(1), 1e-7)
+        if DUMP and (not os.environ.get("FUZZ_DUMP_TRIALS") or str(trial) in os.environ["FUZZ_DUMP_TRIALS"].split(",")):
+            import json
+            os.makedirs(DUMP, exist_ok=True)
+            np.savez_compressed(os.path.join(DUMP, "fuzz%d_trial%d.npz" % (SEED, trial)), x=x, ref=ref,
+                                params=json.dumps(kw12), oracle_opts=json.dumps(o), engine_opts=json.dumps(e),
+                                X_engine=r["X"], status_engine=r["status"], iters_engine=r["iters"],
+                                X_oracle=ro["X"], status_oracle=ro["status"], iters_oracle=ro["iters"])
         if rng.integers(0, 4) == 0 and N <= 30:
             from trajectory_generation_amd import _capi as capi
             op12 = O.mpc12_params(**kw12)
