@@ -348,7 +348,9 @@ def test_step_size_schedule_matches_oracle_and_shortens_tight_runs(tg, oracle):
     N, B = 50, 48
     x0, ref = oracle.synth_mpc6(SEED + 9, N, 0.1, B)
     for kw in (dict(), tight, dict(eps_abs=1e-5, eps_rel=1e-5, check_termination=40, max_iter=8000),
-               dict(phase_iters=(50, 125), phase_scale=((4, 2, 0, 0), (30, 1, 0, 0.5)), **tight)):
+               dict(phase_iters=(50, 125), phase_scale=((4, 2, 0, 0), (30, 1, 0, 0.5)), **tight),
+               # both boundaries fall on the check at iteration 50: the operator between them is never used
+               dict(phase_iters=(20, 45), phase_scale=((0.3, 1, 0, 0), (20, 1, 0, 1)), check_termination=50, eps_abs=1e-6, eps_rel=1e-6, max_iter=5000)):
         eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(**kw))
         r = eng.solve_host(x0, ref)
         oracle.match_engine(eng)

@@ -107,7 +107,7 @@ for trial in range(TRIALS):
                    smooth_input_weight=float(10 ** rng.uniform(-2, 4)), min_altitude=float(rng.uniform(-50, 4)),
                    max_vel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2.5, 3)),
                    max_accel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2.5, 3)))
-    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap")})
+    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap", "phase_iters") if k in e})
     try:
         if ONLY and trial not in ONLY:
             raise KeyError("skipped")
@@ -234,7 +234,7 @@ for trial in range(TRIALS):
                     max_vel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2, 3)),
                     max_accel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2, 3)),
                     max_jerk=tuple(float(v) for v in 10 ** rng.uniform(0, 3, 3)))
-    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap")})
+    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap", "phase_iters") if k in e})
     try:
         if ONLY and trial not in ONLY:
             raise KeyError("skipped")

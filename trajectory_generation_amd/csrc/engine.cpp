@@ -498,12 +498,14 @@ struct DevStage {
         a.count = nullptr; a.next_list = nullptr; a.next_count = nullptr;
         // The step-size schedule: phase p ends at the first check at or after phase_iters[p]; an
         // end at or beyond max_iter never comes.  Without allocation there is one phase only.
-        int bound[2] = {0, 0}, nphase = 1;
+        // Two boundaries that fall on the same check leave the operator between them unused.
+        int bound[2] = {0, 0}, oper[3] = {0, 0, 0}, nphase = 1;
         if (!no_alloc) {
             for (int p = 0; p < (int)later.size(); p++) {
                 const int b = (phase_iters[p] + dev.check - 1) / dev.check * dev.check;
-                if (b >= dev.max_iter || (p > 0 && b <= bound[p - 1])) break;
-                bound[p] = b; nphase = p + 2;
+                if (b >= dev.max_iter) break;
+                if (nphase > 1 && b <= bound[nphase - 2]) { oper[nphase - 1] = p + 1; continue; }
+                bound[nphase - 1] = b; oper[nphase] = p + 1; nphase++;
             }
         }
         if (nphase > 1) {
@@ -528,7 +530,7 @@ struct DevStage {
             }
         }
         for (int p = 0; p < nphase; p++) {
-            StageDev d = p == 0 ? dev : later[p - 1]->dev;
+            StageDev d = oper[p] == 0 ? dev : later[oper[p] - 1]->dev;
             if (p > 0) {   // the run-time settings are those of the stage
                 d.alpha = dev.alpha; d.eps_abs = dev.eps_abs; d.eps_rel = dev.eps_rel; d.eps_prim_inf = dev.eps_prim_inf;
                 d.max_iter = dev.max_iter; d.check = dev.check; d.check_fine = dev.check_fine;
