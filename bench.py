@@ -466,7 +466,13 @@ def main():
     total_inst = float(stats[2].item())
     value = total_inst * timed_steps / elapsed
     stages = iters.shape[0]
-    launches_per_step = stages * (depth if closed else 1)
+    # admm_kernel launches per step: one per stage and operator of the step-size schedule (the later
+    # operators' launches take only the instances handed over to them)
+    if model == "6dof":
+        phases = [tg.phase_launches(eng.get_opts())]
+    else:
+        phases = [tg.phase_launches(eng.get_opts(k)) for k in ("z", "xy", "yaw")]
+    launches_per_step = sum(phases) * (depth if closed else 1)
     if model == "6dof":
         info = [eng.kernel_info()]
         dense = float(iters.sum()) * dense_flops_per_iteration(model, N)
@@ -486,7 +492,7 @@ def main():
         # launches of different handles overlap: the wall time of the region per launch (what one
         # launch costs the device), not the duration of a launch
         avg_kernel_ms = elapsed * 1e3 / (timed_steps * launches_per_step)
-    per_launch_event_ms = kern_ms / max(kern_launches, 1)
+    per_launch_event_ms = kern_ms / max(kern_launches, 1)     # event pairs around a stage's launches (all operators)
     tflops = lambda f: f / (avg_kernel_ms * 1e-3) / 1e12 if avg_kernel_ms > 0 else 0.0
     achieved = tflops(executed)
     traffic = None
@@ -528,7 +534,10 @@ def main():
                      "avg_kernel_ms_is": "event time of the timed region / launches" if depth == 1 else
                                          "wall time of the timed region / launches (launches of the handles in flight overlap)",
                      "launches_timed": timed_steps * launches_per_step,
-                     "per_launch_event_ms": per_launch_event_ms,
+                     "launches_per_solve": phases,
+                     "launches_are": "one admm_kernel launch per stage and operator of the step-size schedule; the launches "
+                                     "of the later operators take only the instances still running then",
+                     "per_stage_solve_event_ms": per_launch_event_ms,
                      "sustained_mfma_microbench": FP64_MFMA_SUSTAINED_TFLOPS,
                      "executed_flops_per_launch": executed,
                      "operator_form": ["lowrank" if i[1] else "dense" for i in info],

@@ -35,7 +35,9 @@ def test_bench_line_single_rank():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     # frac counts the matrix-core flops actually executed: MFMAs per tile-iteration x 2048 / 16 per instance-iteration
     per_it = sum(rf["mfma_per_tile_iteration"]) * 2048 / 16
-    assert abs(rf["executed_flops_per_launch"] - per_it * d["iters_mean"] * 262144) < 1e-6 * rf["executed_flops_per_launch"]
+    # ... shared out over the launches of a solve (one per operator of the step-size schedule)
+    assert rf["launches_per_solve"] == [3] and rf["launches_timed"] == 3 * d["timed_steps"]
+    assert abs(rf["executed_flops_per_launch"] - per_it * d["iters_mean"] * 262144 / 3) < 1e-6 * rf["executed_flops_per_launch"]
     assert 0 < rf["frac"] < 1 and rf["dense_equivalent_tflops"] > rf["achieved"] and d["solved_frac"] == 1.0
     assert d["value"] > 1e6
     cb = d["cpu_baseline"]

@@ -6,10 +6,10 @@ include/tg_mpc.h).  There is no CPU fallback: loading fails loudly when the libr
 """
 from . import _capi
 from .engine import (BatchedMPC6, BatchedMPC12, make_opts, mpc6_params, mpc12_params,
-                     timing_enable, timing_read)
+                     phase_launches, timing_enable, timing_read)
 
 __all__ = ["BatchedMPC6", "BatchedMPC12", "make_opts", "mpc6_params", "mpc12_params",
-           "timing_enable", "timing_read", "MPC", "MPC12STATE"]
+           "phase_launches", "timing_enable", "timing_read", "MPC", "MPC12STATE"]
 
 
 def __getattr__(name):

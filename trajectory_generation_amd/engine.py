@@ -389,6 +389,23 @@ class BatchedMPC12:
         capi.check(self.lib.tg_ref_shift(B, buf["ld"], 12, self.params.N, _ptr(buf["ref"]), _stream_ptr(stream)))
 
 
+def phase_launches(opts):
+    """Kernel launches one solve of a stage makes with these (resolved) options: one per operator of
+    the step-size schedule that can come into use -- boundaries are rounded up to the check interval,
+    must lie below max_iter, and two that coincide count once."""
+    chk, bounds = int(opts.check_termination), []
+    for p in range(2):
+        it = int(opts.phase_iters[p])
+        if it <= 0:
+            break
+        b = (it + chk - 1) // chk * chk
+        if b >= int(opts.max_iter):
+            break
+        if not bounds or b > bounds[-1]:
+            bounds.append(b)
+    return 1 + len(bounds)
+
+
 def timing_enable(on=True):
     capi.load().tg_timing_enable(int(on))
 
