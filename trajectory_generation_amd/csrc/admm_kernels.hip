@@ -135,8 +135,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     bool exhausted = a.queue == nullptr;    // no further instance to take
     bool done = false;
     // instances of this launch: the batch, or (later phases of the step-size schedule) as many
-    // entries of a.list as the previous phase handed over
-    const int Beff = a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.B;
+    // entries of a.list as the previous phase handed over; read where it is needed (start and
+    // refills) rather than kept in a register across the iterations
+    auto batch_size = [&]() __attribute__((always_inline)) -> int { return a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.B; };
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
     // Cell cc of thread group g: linear cell index ax * (N+1) + st, or ncell for an unused slot.
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     };
     {
         const int tk0 = blockIdx.x * kTileDev + t;
-        const int inst0 = tk0 < Beff ? (a.list ? a.list[tk0] : tk0) : a.B;   // a.B: no instance
+        const int inst0 = tk0 < batch_size() ? (a.list ? a.list[tk0] : tk0) : a.B;   // a.B: no instance
         double qf = load(true, inst0);
         if (g == 0) { red[6 * 16 + t] = 0ull; slot_inst[t] = inst0; slot_start[t] = 0; }
         __syncthreads();
@@ -525,12 +526,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     if (__syncthreads_and((done && exhausted) ? 1 : 0)) return;   // nothing to solve in this tile
 
     // One ADMM iteration.  CHK marks an iteration that is followed by a termination check: it
-    // also needs the step delta_y = y+ - y of every row for OSQP's primal infeasibility test.
-    // The dynamics / mixed rows' part goes to WEQ / WMX in place of w (restored after the check),
-    // the thread's own part of A' delta_y stays in registers (part), ||delta_y||_inf and
-    // u'(dy)+ + l'(dy)- are accumulated (pin_n, pin_l).
-    double part[MAXC][S];
-    double pin_n = 0.0, pin_l = 0.0;
+    // also needs the step delta_y = y+ - y of every row for OSQP's primal infeasibility test:
+    // ||delta_y||_inf, u'(dy)+ + l'(dy)- and ||A' delta_y||_inf are accumulated as the rows are
+    // projected (pin_n, pin_l, m_atdy).  A' delta_y of a cell's variables takes delta_y of the
+    // next step's dynamics rows, which belong to another thread: the cell's owner forms them
+    // itself, with the operations their owner uses, from the next cell's xt and its own, so that
+    // nothing has to be kept or exchanged until the check.
+    double pin_n = 0.0, pin_l = 0.0, m_atdy = 0.0;
 #ifdef TG_STAMP
     long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = 0;
     long long chk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, chk_last = 0;   // sections of a termination check; [7] counts them
@@ -965,17 +967,27 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         __syncthreads();
         STAMP(6);
         // -------------------------------------------------------- relaxation, projection, dual
-        if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; }
+        if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; m_atdy = 0.0; }
         {
 #pragma unroll
             for (int c0 = 0; c0 < ((TG_ABLATE & 4) ? 0 : MAXC); c0 += G) {
                 double xt[G][S], xp[G][S], bnd[G][S][2], rr[CHK ? G : 1][S], bg[G][D];
+                double xn[CHK ? G : 1][D], pa[CHK ? G : 1][S], dnx[CHK ? G : 1][D], dm[(CHK && MIXED) ? 6 : 1];   // CHK: next cell's xt, A' delta_y parts
 #pragma unroll
                 for (int j = 0; j < G; j++) {
                     const int cc = c0 + j;
                     if (cc >= MAXC) continue;
                     const double *xin = vx + i_var[cc];
                     const double *xpr = lds + i_prev[cc];
+                    if constexpr (CHK) {
+                        const bool hn = i_wnext[cc] != ZERO + t;          // the cell has a next step
+                        const double *xnx = hn ? xin + S * 16 : lds + ZERO + t;
+#pragma unroll
+                        for (int k = 0; k < D; k++) {
+                            xn[j][k] = xnx[k * 16];
+                            if constexpr (KPART == 2) xn[j][k] += hn ? xin[X2 + (S + k) * 16] : 0.0;
+                        }
+                    }
 #pragma unroll
                     for (int k = 0; k < S; k++) {
                         xt[j][k] = xin[k * 16]; xp[j][k] = xpr[k * 16];
@@ -1003,6 +1015,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         const double u = xt[0][k], v = xt[1][k], up = xp[0][k], vp = xp[1][k];
                         xt[0][k] = u + v; xt[1][k] = u - v; xp[0][k] = up + vp; xp[1][k] = up - vp;
                     }
+                    if constexpr (CHK) {
+#pragma unroll
+                        for (int k = 0; k < D; k++) { const double u = xn[0][k], v = xn[1][k]; xn[0][k] = u + v; xn[1][k] = u - v; }
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < G; j++) {
@@ -1028,7 +1044,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             else if (lo < -kInfBound) d = fmax(d, 0.0);
                             pin_n = fmax(pin_n, fabs(d));
                             pin_l += hi * fmax(d, 0.0) + lo * fmin(d, 0.0);
-                            part[cc][k] = d;
+                            pa[j][k] = d;
                         }
                         if constexpr (SM) zb[cc][k] = s;
                         else { yb[cc][k] = s - zn; zb[cc][k] = zn; }
@@ -1048,12 +1064,29 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             const double d = rho_eq * (zr - b);
                             pin_n = fmax(pin_n, fabs(d));
                             pin_l += b * d;
-                            part[cc][k] -= d;
-                            lds[WEQ + (cw * D + k) * 16 + t] = d;
-                        } else {
-                            lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+                            pa[j][k] -= d;
+                        }
+                        lds[WEQ + (cw * D + k) * 16 + t] = rho_eq * (b - yg[cc][k]);
+                    }
+                    if constexpr (CHK) {
+                        // delta_y of the next step's dynamics rows (their bound is zero: only step 0 has one),
+                        // operation for operation what the owner of that cell computes above
+                        const bool hn = i_wnext[cc] != ZERO + t;
+#pragma unroll
+                        for (int k = 0; k < D; k++) {
+                            double zt = -xn[j][k];
+#pragma unroll
+                            for (int l = k; l < D; l++) zt = __builtin_fma(chain_coef<D>(k, l, dt, c2), xt[j][l], zt);
+                            if (k == D - 1) zt = __builtin_fma(dt, xt[j][D], zt);
+                            const double b = 0.0;
+                            const double zr = __builtin_fma(alpha, zt, oma * b);
+                            dnx[j][k] = hn ? rho_eq * (zr - b) : 0.0;
                         }
                     }
+                }
+                if constexpr (CHK && MIXED) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) dm[k] = 0.0;
                 }
                 if constexpr (MIXED) {
                     // mixed rows of the step (mpc_12state.cpp:600-630) on the xt of both axes
@@ -1076,11 +1109,35 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                                 if (bd > kInfBound) d = 0.0;
                                 pin_n = fmax(pin_n, fabs(d));
                                 pin_l += bd * fabs(d);
-                                lds[i_mw[mm] + k * 16] = d;
-                            } else {
-                                lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zn - ym[mm][k]);
+                                dm[k] = d;
                             }
+                            lds[i_mw[mm] + k * 16] = P.rho_mx[k] * (zn - ym[mm][k]);
                         }
+                    }
+                }
+                if constexpr (CHK) {
+                    // ||A' delta_y||_inf over the cells' variables: own rows + the next step's dynamics
+                    // rows + the step's mixed rows
+#pragma unroll
+                    for (int j = 0; j < G; j++) {
+                        const int cc = c0 + j;
+                        if (cc >= MAXC) continue;
+                        double mixc[3] = {0.0, 0.0, 0.0};
+                        if constexpr (MIXED) {
+                            // axis 0: s3 (d0 + d1) + (d2 - d3) / 2, axis 1: (d0 - d1) / 2 + s3 (d2 + d3)
+                            const bool a0 = axis0[cc];
+                            mixc[1] = s3 * (a0 ? dm[0] + dm[1] : dm[2] + dm[3]) + 0.5 * (a0 ? dm[2] - dm[3] : dm[0] - dm[1]);
+                            mixc[2] = s2 * (a0 ? dm[4] + dm[5] : dm[4] - dm[5]);
+                        }
+#pragma unroll
+                        for (int l = 0; l < D; l++) {
+                            double v = pa[j][l];
+#pragma unroll
+                            for (int k = 0; k <= l; k++) v += chain_coef<D>(k, l, dt, c2) * dnx[j][k];
+                            if (MIXED && l >= 1) v += mixc[l];
+                            m_atdy = fmax(m_atdy, fabs(v));
+                        }
+                        m_atdy = fmax(m_atdy, fabs(pa[j][D] + dt * dnx[j][D - 1]));
                     }
                 }
             }
@@ -1101,8 +1158,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     unsigned phase_mask = 1u;
     // iterations count from the start of an instance's run: a later phase of the step-size schedule
     // takes its instances at iteration phase_start (a multiple of check)
-    const int phase_start = P.phase_start, phase_end = P.phase_end;
-    for (int iter = phase_start;;) {
+    for (int iter = P.phase_start;;) {
         const int gap = (fine > 0 && iter >= check) ? fine : check;
         const int burst = refill ? gap : min(gap, max_iter - iter);
         for (int i = 1; i < burst; i++) {
@@ -1122,33 +1178,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             CSTAMP(0);
             asm volatile("" : "+v"(gq));
             __syncthreads();
-            // ||A' delta_y||_inf: own part + the next step's dynamics rows + the mixed rows
-            double m_atdy = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < (full ? MAXC : 0); cc++) {
-                double dn[D], mixc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-                for (int k = 0; k < D; k++) dn[k] = lds[i_wnext[cc] + k * 16];
-                if (MIXED) {
-                    const double *wm = lds + i_mx[cc];
-                    const double w0 = wm[0], w1 = wm[16], w2 = wm[32], w3 = wm[48], w4 = wm[64], w5 = wm[80];
-                    // axis 0: s3 (w0 + w1) + (w2 - w3) / 2, axis 1: (w0 - w1) / 2 + s3 (w2 + w3); selecting
-                    // the sums keeps the coefficients compile-time constants instead of per-lane registers
-                    const bool a0 = axis0[cc];
-                    mixc[1] = s3 * (a0 ? w0 + w1 : w2 + w3) + 0.5 * (a0 ? w2 - w3 : w0 - w1);
-                    mixc[2] = s2 * (a0 ? w4 + w5 : w4 - w5);
-                }
-#pragma unroll
-                for (int l = 0; l < D; l++) {
-                    double v = part[cc][l];
-#pragma unroll
-                    for (int k = 0; k <= l; k++) v += chain_coef<D>(k, l, dt, c2) * dn[k];
-                    if (MIXED && l >= 1) v += mixc[l];
-                    m_atdy = fmax(m_atdy, fabs(v));
-                }
-                m_atdy = fmax(m_atdy, fabs(part[cc][D] + dt * dn[D - 1]));
-            }
-            if (full) __syncthreads();
             if (g == 0) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) if (k != 6) red[k * 16 + t] = 0ull;
@@ -1311,7 +1340,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
             // an instance still running at the end of this launch's phase moves on to the next
             // operator: its iterates go to the warm rows and its number to the next launch's list
             const bool fin = conv || pinf || last;
-            const bool pexit = !fin && a.next_list != nullptr && local >= phase_end;
+            const bool pexit = !fin && a.next_list != nullptr && local >= P.phase_end;
             CSTAMP(3);
             if (!done && (fin || pexit)) {
                 done = true;
@@ -1443,7 +1472,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     base = __shfl(base, 0);
                     if (need && g == 0) {
                         const int ni = a.queue_base + base + (int)__popcll(mask & ((1ull << t) - 1ull));
-                        next[t] = ni < Beff ? (a.list ? a.list[ni] : ni) : -1;
+                        next[t] = ni < batch_size() ? (a.list ? a.list[ni] : ni) : -1;
                         red[6 * 16 + t] = 0ull;
                     }
                 }
@@ -1456,10 +1485,10 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                 double qf = load(fresh, ni);
                 qf = wave_gmax(qf);
                 if (fresh && (lane >> 4) == 0) lds_max(&red[6 * 16 + t], qf);
-                if (fresh && g == 0) { slot_inst[t] = ni; slot_start[t] = iter - phase_start; }
+                if (fresh && g == 0) { slot_inst[t] = ni; slot_start[t] = iter - P.phase_start; }
                 if (fine > 0) {
                     // bitwise OR over the live slots (__syncthreads_or only tells whether any bit is set)
-                    const int st0 = fresh ? iter - phase_start : slot_start[t];
+                    const int st0 = fresh ? iter - P.phase_start : slot_start[t];
                     if (g == 0 && !done) atomicOr((unsigned *)&next[16], 1u << ((st0 / fine) % nphase));
                     __syncthreads();
                     phase_mask = (unsigned)next[16];
