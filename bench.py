@@ -257,6 +257,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0,
                     help="batches in flight: consecutive steps go round-robin to this many handles, each with its own "
                          "buffers and HIP stream (0: the workload's default; 1: one handle, steps strictly in turn)")
+    ap.add_argument("--no-schedule", action="store_true", help="first operator only: no step-size schedule (phase_iters = -1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the second leg (rate at the tolerance that lands within 1e-4 of a converged run)")
     ap.add_argument("--no-check-fine", action="store_true", help="skip the second figure with the finer schedule of checks (check_fine_5)")
@@ -310,8 +311,9 @@ def main():
         first, B = synth.shard(count, rank, world)         # fixed total: every rank owns a slab of it
     else:
         first, B = rank * count, count                     # fixed per GPU: every rank owns its own slab
+    sched = dict(phase_iters=(-1, -1)) if args.no_schedule else {}
     opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check,
-                        check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank, hard_first=args.hard_first)
+                        check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank, hard_first=args.hard_first, **sched)
     closed = args.workload.startswith("rollout")
     # A batch that is one wave of workgroups (B = 4096: 256 tiles on 256 CUs) ends with the chip
     # waiting for its slowest tile; a server keeps the next batches in flight meanwhile.  Steps go
@@ -514,6 +516,8 @@ def main():
                    "eps_abs": args.eps, "eps_rel": args.eps, "max_iter": args.max_iter, "check_termination": args.check,
                    "check_fine": args.check_fine, "grid_cap": args.grid_cap, "lowrank": args.lowrank, "hard_first": args.hard_first,
                    "smoothing": bool(args.smoothing), "inputs": "stress" if args.stress else "seeded",
+                   "phase_iters": [[int(v) for v in (eng.get_opts() if model == "6dof" else eng.get_opts(k)).phase_iters]
+                                   for k in (("6dof",) if model == "6dof" else ("z", "xy", "yaw"))],
                    "rho": eng.rho if model == "6dof" else [eng.rho(k) for k in ("xy", "z", "yaw")],
                    "parallelism": "instances sharded x%d" % world, "batches_in_flight": depth,
                    "instances_per_handle": Bh},
@@ -542,7 +546,8 @@ def main():
                      "executed_flops_per_launch": executed,
                      "operator_form": ["lowrank" if i[1] else "dense" for i in info],
                      "mfma_per_tile_iteration": [i[0] for i in info],
-                     "algorithmic_bytes_per_launch": 8.0 * B * (eng.nx + eng.nx * (N + 1) + (eng.nx + eng.nu) * N + eng.nx),
+                     "algorithmic_bytes_per_launch": 8.0 * B * (eng.nx + eng.nx * (N + 1) + (eng.nx + eng.nu) * N + eng.nx) / sum(phases),
+                     "algorithmic_bytes_per_solve": 8.0 * B * (eng.nx + eng.nx * (N + 1) + (eng.nx + eng.nu) * N + eng.nx),
                      "dense_equivalent_tflops": tflops(dense),
                      "dense_equivalent_flops_per_iteration": dense_flops_per_iteration(model, N),
                      "monolithic_flops_per_iteration": mono,
@@ -617,7 +622,7 @@ def target_accuracy_leg(tg, torch, dist, model, N, args, local, world, red_dev, 
     eng = mk(par(N=N, enable_control_smoothing=args.smoothing),
              tg.make_opts(eps_abs=TARGET_LADDER[-1], eps_rel=TARGET_LADDER[-1], max_iter=TARGET_MAX_ITER,
                           check_termination=args.check, grid_cap=args.grid_cap, lowrank=args.lowrank,
-                          hard_first=args.hard_first), device=local)
+                          hard_first=args.hard_first, **(dict(phase_iters=(-1, -1)) if args.no_schedule else {})), device=local)
     stage0 = () if model == "6dof" else ("xy",)
 
     def set_eps(eps, max_iter):

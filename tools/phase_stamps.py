@@ -13,7 +13,7 @@ iters = int(sys.argv[3]) if len(sys.argv) > 3 else 200
 CHK = int(sys.argv[4]) if len(sys.argv) > 4 else iters
 REAL = len(sys.argv) > 5 and sys.argv[5] == "real"     # eps 1e-3 on a batch of 32768: exits and slot refills included
 B = 32768 if REAL else 4096
-opts = tg.make_opts() if REAL else tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=CHK, eps_prim_inf=0.0)
+opts = tg.make_opts(phase_iters=(-1, -1)) if REAL else tg.make_opts(eps_abs=0.0, eps_rel=0.0, max_iter=iters, check_termination=CHK, eps_prim_inf=0.0, phase_iters=(-1, -1))
 if model == "6dof":
     eng = tg.BatchedMPC6(tg.mpc6_params(N=N), opts)
     x0, ref = synth.mpc6(1, N, 0.1, B)

@@ -20,7 +20,7 @@ def main(src, dst_prefix, workload):
     lines = []
     db = one_db(os.path.join(src, "trace"))
     if db:
-        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s --steps 200 --no-cpu-baseline" % workload)
+        lines.append("rocprofv3 --kernel-trace --stats -- python3 bench.py --workload %s %s" % (workload, os.environ.get("PROF_ARGS", "")))
         lines.append("%-90s %8s %14s %12s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
         for name, calls, total, avg, pct in db.execute("select * from top_kernels"):
             lines.append("%-90s %8d %14.1f %12.2f %8.3f" % (name[:90], calls, total, avg, pct))
@@ -65,7 +65,9 @@ def main(src, dst_prefix, workload):
         lines.append("rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS "
                      "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE (means per launch)")
         sq = {}
-        for k, c, v, n in db.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection "
+        # sums over all launches of a kernel: the ratios below are then weighted by launch length (a solve
+        # makes one launch per operator of the step-size schedule, the later ones short)
+        for k, c, v, n in db.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
                                      "where kernel_name like '%admm_kernel%' group by kernel_name, counter_name"):
             sq.setdefault(k, {})[c] = v
             sq[k]["launches"] = n
@@ -79,14 +81,14 @@ def main(src, dst_prefix, workload):
                  "mfma_pipe_busy_frac": d["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui),
                  "lds_array_busy_frac": d["SQ_LDS_IDX_ACTIVE"] / (256.0 * gui),
                  "lds_bank_conflict_frac_of_lds_cycles": d["SQ_LDS_BANK_CONFLICT"] / max(d["SQ_LDS_IDX_ACTIVE"], 1.0),
-                 "mfma_instructions": d["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0, "kernel_cycles": gui}
+                 "mfma_instructions": d["SQ_VALU_MFMA_BUSY_CYCLES"] / 64.0 / d["launches"], "kernel_cycles": gui / d["launches"]}
             out["sq"][k] = o
             lines.append(k[:100])
-            lines.append("  launches %d, %.0f shader cycles per launch" % (o["launches"], gui))
+            lines.append("  launches %d, %.0f shader cycles per launch (mean)" % (o["launches"], gui / d["launches"]))
             lines.append("  wave time: parked at s_waitcnt / barrier %.1f %%, stalled at issue %.1f %% (of which LDS %.1f %%), issuing %.1f %%"
                          % (100 * o["wave_parked_frac"], 100 * o["wave_issue_stall_frac"], 100 * o["wave_lds_issue_stall_frac"],
                             100 * o["wave_issuing_frac"]))
-            lines.append("  MFMA pipe busy %.1f %% of SIMD cycles (%.0f MFMAs), LDS array busy %.1f %% of CU cycles, bank conflicts %.2f %% of LDS cycles"
+            lines.append("  MFMA pipe busy %.1f %% of SIMD cycles (%.0f MFMAs per launch), LDS array busy %.1f %% of CU cycles, bank conflicts %.2f %% of LDS cycles"
                          % (100 * o["mfma_pipe_busy_frac"], o["mfma_instructions"], 100 * o["lds_array_busy_frac"],
                             100 * o["lds_bank_conflict_frac_of_lds_cycles"]))
     os.makedirs(os.path.dirname(dst_prefix), exist_ok=True)

@@ -83,8 +83,7 @@ inline double default_rho(const StageModel &mdl)
     // Fixed step size used in place of OSQP's adaptive rho on the equilibrated problem: half the
     // geometric mean of the largest state weight and the input weight, rounded to 1-2-5
     // (7000/500 -> 1000, 7000/200 and 5000/200 -> 500, 1000/100 -> 200).  The factor and the
-    // per-class multipliers below come from the same sweeps (tools/sweep12.py for the 12-state
-    // stages).
+    // per-class multipliers below come from the same sweeps over seeded instances.
     double w = 0;
     for (int a = 0; a < mdl.nx; a++) w = std::max(w, mdl.qdiag[a]);
     double g = 0.5 * std::sqrt(std::max(w, 1e-12) * std::max(mdl.r, 1e-12));
@@ -182,7 +181,7 @@ inline void column_space(const std::vector<long double> &R, int rows, int cols, 
 // A uniform rho leaves a long iteration tail on instances whose position or input rows are
 // active (the 6-DOF altitude floor, saturated inputs): the step those rows need is set by the
 // state / input weights, not by their geometric mean.  Values picked from sweeps over seeded
-// random instances at N = 20 and N = 50 (tools/gpu_rho_sweep.py, tools/iter_need.py, tools/rho_hist.py):
+// random instances at N = 20 and N = 50 (held-out seeds; tools/rho_policy_probe.py runs such sweeps):
 // 6-DOF N = 20: slowest instance 375 -> 30 iterations at eps 1e-3, 99.9 % done at the first check
 // (iteration 25).  N = 50: (12, 3, 1, 4) passes the first check with 93.5 % of the instances, mean
 // 26.8 iterations, slowest of 8192 at 125-225 depending on the seed; a larger step on the altitude
