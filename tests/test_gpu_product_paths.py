@@ -696,3 +696,56 @@ def test_hard_first_order_12state_chain(tg):
     ok = (a["status"].reshape(3, -1)[:, :B] == 1).all(0)
     assert 0.99 * B < int(ok.sum()) < B               # the batch holds gated instances too
     assert torch.equal(a["X"][:, :B][:, ok], b["X"][:, :B][:, ok]) and torch.equal(a["U"][:, :B][:, ok], b["U"][:, :B][:, ok])
+
+
+def test_config5_share_closed_loop_properties(tg):
+    """The per-GPU share of the closed-loop configuration (12-state, 8192 vehicles, N = 20, warm
+    start, gated plant, reference shift) over 60 steps, checked through what does not depend on the
+    size: every step's state is exactly the plant's image of the previous one under that step's
+    first control (x+ = A x + B u(0), test_mpc_12state.cpp:193-197), the controls respect the jerk
+    limits, speeds and accelerations stay within their limits up to the solver tolerance, vehicles
+    close in on their moving targets, and failures stay rare."""
+    import torch
+    from trajectory_generation_amd import _capi as capi, synth
+    from trajectory_generation_amd.mpc_12state import MPC12STATE
+    N, B, steps = 20, 8192, 60
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N))
+    A = MPC12STATE._blkdiag(*[eng.get(s_, capi.TG_MAT_AD) for s_ in ("xy", "z", "yaw")])
+    Bm = MPC12STATE._blkdiag(*[eng.get(s_, capi.TG_MAT_BD) for s_ in ("xy", "z", "yaw")])
+    x0, ref = synth.mpc12(SEED + 5, N, 0.1, B)
+    buf = eng.alloc(B)
+    _to_dev(buf, x0, ref)
+    eng.reset_warm()
+    At, Bt = torch.from_numpy(A).cuda(), torch.from_numpy(Bm).cuda()
+    err0 = None
+    failed_steps = 0
+    worst_plant = worst_u = worst_v = worst_a = 0.0
+    for k in range(steps):
+        x = buf["x0"][:, :B].clone()
+        eng.solve(buf, warm=True)
+        ok = (buf["status"][:, :B] == 1).all(0)
+        failed_steps += int((~ok).sum().item())
+        eng.plant_step(buf)
+        u0 = buf["U"][:4, :B]                       # what the gated plant applied (a failed vehicle's plan has moved up)
+        pred = At @ x + Bt @ u0
+        worst_plant = max(worst_plant, float((buf["x0"][:, :B] - pred).abs().max().item()))
+        worst_u = max(worst_u, float((u0[:2].abs().max() / 30.0).item()), float((u0[2].abs().max() / 40.0).item()),
+                      float((u0[3].abs().max() / 10.0).item()))
+        xs = buf["x0"][:, :B]
+        worst_v = max(worst_v, float((xs[7].abs().max() / 7.0).item()), float((xs[10].abs().max() / 2.0).item()))
+        worst_a = max(worst_a, float((xs[8].abs().max() / 10.0).item()), float((xs[11].abs().max() / 10.0).item()),
+                      float((torch.maximum(xs[2].abs(), xs[5].abs()).max() / 6.0).item()))
+        tgt = buf["ref"][:, :B].reshape(N + 1, 12, B)[1]          # where the target is at the new time
+        err = torch.sqrt((tgt[0] - xs[0]) ** 2 + (tgt[3] - xs[3]) ** 2 + (tgt[6] - xs[6]) ** 2)
+        if err0 is None:
+            err0 = err.clone()
+        eng.ref_shift(buf)
+    torch.cuda.synchronize()
+    # the plant update itself carries only rounding (a failed vehicle's u(0) is read after its plan moved up)
+    assert worst_plant < 1e-9, worst_plant
+    assert worst_u <= 1.0 + 1e-3 and worst_v <= 1.0 + 2e-2 and worst_a <= 1.0 + 2e-2, (worst_u, worst_v, worst_a)
+    assert failed_steps <= 0.005 * B * steps, failed_steps
+    # after six seconds most vehicles have caught up with their targets (8 m + 3 m/s of lead at the start)
+    assert float(err.median().item()) < 0.25 * float(err0.median().item()), (float(err.median().item()), float(err0.median().item()))
+    print("closed loop 8192 x %d: failed vehicle-steps %d, distance to target median %.2f -> %.2f m, limits used u %.3f v %.3f a %.3f"
+          % (steps, failed_steps, float(err0.median().item()), float(err.median().item()), worst_u, worst_v, worst_a))
