@@ -249,7 +249,7 @@ def main():
     ap.add_argument("--grid-cap", type=int, default=0, help="most workgroups per solve (0: what the GPU holds at once, -1: one per tile of 16 instances)")
     ap.add_argument("--lowrank", type=int, default=0, help="K^-1 as diagonal tiles + low-rank rest: 0 where it pays, 1 wherever possible, -1 dense")
     ap.add_argument("--check-fine", type=int, default=0, help="check interval after the first check (0: OSQP's fixed interval, the default everywhere)")
-    ap.add_argument("--hard-first", type=int, default=0, help="a refilled grid takes the likely slow instances first (0) or the batch in its own order (-1)")
+    ap.add_argument("--hard-first", type=int, default=0, help="a refilled grid takes the likely slow instances first (1), the batch in its own order (-1), or whichever pays (0: the former without a step-size schedule)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the multi-rank path with several ranks on one GPU")
     ap.add_argument("--smoothing", action="store_true", help="input smoothing term on (the test mains' setting; config/mpc.yaml has it off)")
@@ -258,6 +258,7 @@ def main():
                     help="batches in flight: consecutive steps go round-robin to this many handles, each with its own "
                          "buffers and HIP stream (0: the workload's default; 1: one handle, steps strictly in turn)")
     ap.add_argument("--no-schedule", action="store_true", help="first operator only: no step-size schedule (phase_iters = -1)")
+    ap.add_argument("--phase-iters", default="", help="two iteration counts 'a,b' for the step-size schedule in place of the built-in ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the second leg (rate at the tolerance that lands within 1e-4 of a converged run)")
     ap.add_argument("--no-check-fine", action="store_true", help="skip the second figure with the finer schedule of checks (check_fine_5)")
@@ -312,6 +313,8 @@ def main():
     else:
         first, B = rank * count, count                     # fixed per GPU: every rank owns its own slab
     sched = dict(phase_iters=(-1, -1)) if args.no_schedule else {}
+    if args.phase_iters:
+        sched = dict(phase_iters=tuple(int(v) for v in args.phase_iters.split(",")))
     opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check,
                         check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank, hard_first=args.hard_first, **sched)
     closed = args.workload.startswith("rollout")
@@ -471,9 +474,9 @@ def main():
     # admm_kernel launches per step: one per stage and operator of the step-size schedule (the later
     # operators' launches take only the instances handed over to them)
     if model == "6dof":
-        phases = [tg.phase_launches(eng.get_opts())]
+        phases = [tg.phase_launches(eng.get_opts(), Bh)]
     else:
-        phases = [tg.phase_launches(eng.get_opts(k)) for k in ("z", "xy", "yaw")]
+        phases = [tg.phase_launches(eng.get_opts(k), Bh) for k in ("z", "xy", "yaw")]
     launches_per_step = sum(phases) * (depth if closed else 1)
     if model == "6dof":
         info = [eng.kernel_info()]

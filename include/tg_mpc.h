@@ -109,9 +109,11 @@ typedef struct {
      * -1: dense always.  The two forms agree to rounding (1e-15 relative). */
     int    lowrank;
     /* Order in which a grid whose slots are refilled (grid_cap above) takes the instances of the
-     * batch.  0: the sixteenth of the batch whose reference strays farthest from where the initial
+     * batch.  1: the sixteenth of the batch whose reference strays farthest from where the initial
      * state coasts to is taken first -- those instances tend to need the most iterations, and
-     * started last they would leave the GPU waiting for them; -1: batch order.  An instance's
+     * started last they would leave the GPU waiting for them; -1: batch order; 0: where it pays,
+     * which is on handles without a step-size schedule (phase_iters below: with one, an instance
+     * leaves the first launch after phase_iters[0] iterations wherever it started).  An instance's
      * result does not depend on it. */
     int    hard_first;
     /* Step-size schedule, in place of OSQP's run-time rho adaptation.  A handle holds up to three

@@ -642,28 +642,32 @@ def test_handles_on_their_own_streams_overlap_without_interfering(tg):
 
 # ---------------------------------------------------------------- order in which a refilled grid takes the batch
 def test_hard_first_order_changes_nothing_but_the_order(tg):
-    """A refilled grid takes the sixteenth of the batch that is likely to need the most iterations
-    first (tg_solver_opts.hard_first, default).  Statuses, iteration counts and solutions equal
-    those in batch order bit for bit, with an infeasible instance in the batch; and the
-    instances that needed the most iterations are indeed among those the ordering puts first."""
+    """A refilled grid can take the sixteenth of the batch that is likely to need the most iterations
+    first (tg_solver_opts.hard_first = 1; the default where there is no step-size schedule).
+    Statuses, iteration counts and solutions equal those in batch order bit for bit, with an
+    infeasible instance in the batch, with and without a schedule; and the instances that needed
+    the most iterations are indeed among those the ordering puts first."""
     import torch
     from trajectory_generation_amd import synth
     N, B = 50, 8192
     x0, ref = synth.mpc6(SEED + 4, N, 0.1, B)
     x0[4321, 4] = -40.0                               # |v_y(0)| > v_max: infeasible
-    res = []
-    for hf in (-1, 0):
-        eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(hard_first=hf))
-        assert eng.get_opts().hard_first == hf
-        buf = eng.alloc(B)
-        _to_dev(buf, x0, ref)
-        eng.solve(buf)
-        res.append({k: buf[k].clone() for k in ("X", "U", "status", "iters")})
-    a, b = res
-    assert torch.equal(a["status"], b["status"]) and torch.equal(a["iters"], b["iters"])
-    ok = a["status"][:B] == 1
-    assert int(ok.sum()) == B - 1 and int(a["status"][4321]) == -3
-    assert torch.equal(a["X"][:, :B][:, ok], b["X"][:, :B][:, ok]) and torch.equal(a["U"][:, :B][:, ok], b["U"][:, :B][:, ok])
+    for sched in ((-1, -1), (0, 0)):
+        res = []
+        for hf in (-1, 1, 0):
+            eng = tg.BatchedMPC6(tg.mpc6_params(N=N), tg.make_opts(hard_first=hf, phase_iters=sched))
+            assert eng.get_opts().hard_first == hf
+            buf = eng.alloc(B)
+            _to_dev(buf, x0, ref)
+            eng.solve(buf)
+            res.append({k: buf[k].clone() for k in ("X", "U", "status", "iters")})
+        a = res[0]
+        ok = a["status"][:B] == 1
+        assert int(ok.sum()) == B - 1 and int(a["status"][4321]) == -3
+        for b in res[1:]:
+            assert torch.equal(a["status"], b["status"]) and torch.equal(a["iters"], b["iters"])
+            assert torch.equal(a["X"][:, :B][:, ok], b["X"][:, :B][:, ok]) and torch.equal(a["U"][:, :B][:, ok], b["U"][:, :B][:, ok])
+    a = res[0]
     # the score the ordering uses: farthest the reference strays from where the initial state coasts to
     t = np.arange(N + 1) * 0.1
     R = ref.reshape(B, N + 1, 6)[:, :, :3]
@@ -685,7 +689,7 @@ def test_hard_first_order_12state_chain(tg):
     N, B = 20, 8192
     x, ref = synth.mpc12(SEED + 3, N, 0.1, B)
     res = []
-    for hf in (-1, 0):
+    for hf in (-1, 1):
         eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(hard_first=hf))
         buf = eng.alloc(B)
         _to_dev(buf, x, ref)

@@ -465,7 +465,11 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     };
     {
         const int tk0 = blockIdx.x * kTileDev + t;
-        const int inst0 = tk0 < batch_size() ? (a.list ? a.list[tk0] : tk0) : a.B;   // a.B: no instance
+        const int nb_ = batch_size();
+        // nothing beyond the slots' first instances (a later operator's launch finds few, or none):
+        // no refill to wait for -- a workgroup without instances leaves at once
+        if (a.queue != nullptr && a.queue_base >= nb_) exhausted = true;
+        const int inst0 = tk0 < nb_ ? (a.list ? a.list[tk0] : tk0) : a.B;   // a.B: no instance
         double qf = load(true, inst0);
         if (g == 0) { red[6 * 16 + t] = 0ull; slot_inst[t] = inst0; slot_start[t] = 0; }
         __syncthreads();

@@ -489,11 +489,6 @@ struct DevStage {
             a.queue_mem = grid_cap >= 0 ? d_queue : nullptr;
         }
         a.list = nullptr; a.order_list = nullptr; a.order_score = nullptr; a.order_hdr = nullptr;
-        if (!no_alloc && grid_cap >= 0 && hard_first >= 0 && a.B > 16 * 256) {   // smaller batches never go through the queue
-            int rc = ensure_order(a.B);
-            if (rc) return rc;
-            a.order_list = d_olist; a.order_score = d_oscore; a.order_hdr = d_ohdr;
-        }
         a.grid_cap = grid_cap;
         a.count = nullptr; a.next_list = nullptr; a.next_count = nullptr;
         // The step-size schedule: phase p ends at the first check at or after phase_iters[p]; an
@@ -507,6 +502,15 @@ struct DevStage {
                 if (nphase > 1 && b <= bound[nphase - 2]) { oper[nphase - 1] = p + 1; continue; }
                 bound[nphase - 1] = b; oper[nphase] = p + 1; nphase++;
             }
+        }
+        // Likely slow instances first (hard_first): 1 always, 0 where it pays -- without a schedule.  With
+        // one the slow instances leave the first launch after phase_iters[0] iterations wherever they
+        // started, and ordering the batch costs more than it saves (N = 50, 262144 instances: 14.5
+        // against 14.2 ms).
+        if (!no_alloc && grid_cap >= 0 && (hard_first > 0 || (hard_first == 0 && nphase == 1)) && a.B > 16 * 256) {   // smaller batches never go through the queue
+            int rc = ensure_order(a.B);
+            if (rc) return rc;
+            a.order_list = d_olist; a.order_score = d_oscore; a.order_hdr = d_ohdr;
         }
         if (nphase > 1) {
             int rc = ensure_warm(a.B, s);         // the hand-over travels through the warm rows
@@ -529,26 +533,34 @@ struct DevStage {
                 return fail(TG_E_HIP, "timing events could not be created");
             }
         }
-        for (int p = 0; p < nphase; p++) {
-            StageDev d = oper[p] == 0 ? dev : later[oper[p] - 1]->dev;
-            if (p > 0) {   // the run-time settings are those of the stage
-                d.alpha = dev.alpha; d.eps_abs = dev.eps_abs; d.eps_rel = dev.eps_rel; d.eps_prim_inf = dev.eps_prim_inf;
-                d.max_iter = dev.max_iter; d.check = dev.check; d.check_fine = dev.check_fine;
+        // the chain of launches: every operator of the schedule in turn, each taking what the one
+        // before handed over
+        auto chain = [&](const BatchArgs &first, int *const plist[2], int *pcount, hipStream_t st) -> int {
+            for (int p = 0; p < nphase; p++) {
+                StageDev d = oper[p] == 0 ? dev : later[oper[p] - 1]->dev;
+                if (p > 0) {   // the run-time settings are those of the stage
+                    d.alpha = dev.alpha; d.eps_abs = dev.eps_abs; d.eps_rel = dev.eps_rel; d.eps_prim_inf = dev.eps_prim_inf;
+                    d.max_iter = dev.max_iter; d.check = dev.check; d.check_fine = dev.check_fine;
+                }
+                d.phase_start = p > 0 ? bound[p - 1] : 0;
+                d.phase_end = p + 1 < nphase ? bound[p] : INT_MAX;
+                BatchArgs ap = first;
+                if (p > 0) {
+                    ap.count = pcount + (p - 1); ap.list = plist[(p - 1) & 1]; ap.warm_in = 1;
+                    ap.order_list = nullptr; ap.order_score = nullptr; ap.order_hdr = nullptr;
+                }
+                if (p + 1 < nphase) { ap.next_list = plist[p & 1]; ap.next_count = pcount + p; }
+                hipError_t e = launch_admm(d, ap, st, &why);
+                if (e != hipSuccess)
+                    return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
+                                std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
             }
-            d.phase_start = p > 0 ? bound[p - 1] : 0;
-            d.phase_end = p + 1 < nphase ? bound[p] : INT_MAX;
-            BatchArgs ap = a;
-            if (p > 0) {
-                ap.count = d_pcount + (p - 1); ap.list = d_plist[(p - 1) & 1]; ap.warm_in = 1;
-                ap.order_list = nullptr; ap.order_score = nullptr; ap.order_hdr = nullptr;
-            }
-            if (p + 1 < nphase) { ap.next_list = d_plist[p & 1]; ap.next_count = d_pcount + p; }
-            hipError_t e = launch_admm(d, ap, s, &why);
-            if (e != hipSuccess) {
-                if (timing) { hipEventDestroy(e0); hipEventDestroy(e1); }
-                return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
-                            std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
-            }
+            return TG_OK;
+        };
+        const int crc = chain(a, d_plist, d_pcount, s);
+        if (crc != TG_OK) {
+            if (timing) { hipEventDestroy(e0); hipEventDestroy(e1); }
+            return crc;
         }
         if (timing) {
             if (hipEventRecord(e1, s) != hipSuccess) {

@@ -25,7 +25,8 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
     grid_cap: most workgroups a solve launches (0: what the GPU holds at once, < 0: one per tile of
     16 instances); a smaller grid refills its instance slots from the rest of the batch;
     lowrank: K^-1 as diagonal tiles + low-rank rest (0: where it pays, 1: wherever possible, -1: dense).
-    hard_first: a refilled grid takes the likely slow instances first (0; -1: batch order).
+    hard_first: a refilled grid takes the likely slow instances first (1), the batch in its order (-1),
+    or whichever pays (0: the former on handles without a step-size schedule).
     phase_iters / phase_scale: the step-size schedule -- an instance still running at the first check
     at or after phase_iters[p] continues under an operator whose class multipliers are rho_scale x
     phase_scale[p] (0: built-in choice, phase_iters < 0: no such phase)."""
@@ -389,7 +390,7 @@ class BatchedMPC12:
         capi.check(self.lib.tg_ref_shift(B, buf["ld"], 12, self.params.N, _ptr(buf["ref"]), _stream_ptr(stream)))
 
 
-def phase_launches(opts):
+def phase_launches(opts, B=None):
     """Kernel launches one solve of a stage makes with these (resolved) options: one per operator of
     the step-size schedule that can come into use -- boundaries are rounded up to the check interval,
     must lie below max_iter, and two that coincide count once."""
