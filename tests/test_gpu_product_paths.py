@@ -340,6 +340,7 @@ def test_step_size_schedule_matches_oracle_and_shortens_tight_runs(tg, oracle):
     o = opts(50)
     assert tuple(o.phase_iters) == (100, 200) and tuple(o.phase_scale[0]) == (8.0, 1.0, 1.0, 1.0) and tuple(o.phase_scale[1]) == (64.0, 1.0, 1.0, 1.0)
     assert tuple(opts(50, **tight).rho_scale) == tuple(o.rho_scale) == (12.0, 3.0, 1.0, 4.0)
+    assert tuple(opts(20).phase_iters) == (-1, -1)          # short horizons have no tail worth a second operator
     o = opts(50, phase_iters=(150, -1), phase_scale=((0, 5, 0, 0), (0, 0, 0, 0)))
     assert tuple(o.phase_iters) == (150, -1) and tuple(o.phase_scale[0]) == (8.0, 5.0, 1.0, 1.0)
     assert tuple(opts(50, phase_iters=(-1, 300)).phase_iters) == (-1, -1)

@@ -20,6 +20,8 @@ done
 # summaries are made on the box (the databases stay there: only text / JSON travels back)
 cd $R
 for w in ${WORKLOADS:-mpc_6dof_B262144_N50 mpc_6dof_B4096_N20 mpc_12state_B4096_N20}; do
+  steps=200; case $w in mpc_6dof_B262144_N50) steps=10;; esac
+  export PROF_ARGS="--steps $steps --warmup 2 --no-cpu-baseline --no-target-leg $EXTRA"
   python3 tools/prof_summary.py gpurun_out/prof_$ROUND/$w gpurun_out/prof_${ROUND}_sum/${ROUND}_$w$TAG $w > gpurun_out/prof_$ROUND/$w.summary.log 2>&1
   grep "^{" gpurun_out/prof_$ROUND/$w.trace.log > gpurun_out/prof_${ROUND}_sum/${ROUND}_${w}${TAG}_bench_line.json
   rm -rf gpurun_out/prof_$ROUND/$w

@@ -214,6 +214,10 @@ inline void default_phases(const StageModel &mdl, int iters[2], double scale[2][
         for (int k = 0; k < 4; k++) scale[p][k] = 1.0;
     }
     if (mdl.family == TG_FAM_6DOF) {
+        // (short horizons have no such tail: N = 20 needs 75 iterations at eps 1e-9 and at most 225 with
+        // or without a schedule, and two continuation launches that find nothing would cost a batch of
+        // 4096 a tenth of its 0.12 ms)
+        if (mdl.N <= 30) return;
         iters[0] = 100; scale[0][0] = 8.0;
         iters[1] = 200; scale[1][0] = 64.0;
     } else if (mdl.family == TG_FAM_XY) {
