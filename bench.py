@@ -684,9 +684,10 @@ def target_accuracy_leg(tg, torch, dist, model, N, args, local, world, red_dev, 
                 eng.solve(buf)
             torch.cuda.synchronize(); barrier()
             return reduce([time.perf_counter() - t0], dist.ReduceOp.MAX)[0]
-        elapsed, steps = 0.0, 0
-        while (elapsed < TARGET_MIN_TIMED_S and steps < 200 * TARGET_MIN_STEPS) or steps == 0:
-            elapsed += region(TARGET_MIN_STEPS); steps += TARGET_MIN_STEPS
+        elapsed, steps, k = 0.0, 0, TARGET_MIN_STEPS
+        while elapsed < TARGET_MIN_TIMED_S:             # regions grow, so that small batches reach the floor as well
+            elapsed += region(k); steps += k
+            k = min(2 * k, 4096)
         it = buf["iters"].reshape(-1, ld)[:, :B]
         stages = it.shape[0]
         info = [eng.kernel_info()] if model == "6dof" else [eng.kernel_info(k) for k in ("z", "xy", "yaw")]

@@ -607,6 +607,57 @@ mpc_node:
     assert abs(msg.command.acceleration.x - ro["U"][0][0]) < 1e-9 and msg.max_velocity == 10.0
 
 
+def test_yaml_to_engine_to_messages_12state(tg, oracle, tmp_path):
+    """The same chain for the 12-state node: config/mpc_12state.yaml's key names -> MPC12STATE
+    look-alike (mpc_12state_ros.cpp:37-121) -> the three-stage solve on the GPU -> message-shaped view
+    (mpc_12state_ros.cpp:410-501), against the oracle's chain configured with the same numbers."""
+    from trajectory_generation_amd.config import configure_mpc12
+    from trajectory_generation_amd.messages import from_mpc12
+    N, dt = 8, 0.1
+    vals = dict(state_weight=(4000.0, 6000.0, 900.0), input_weight=(150.0, 250.0, 80.0), smooth_input_weight=(100.0, 100.0, 100.0),
+                max_vel=(11.0, 6.0, 2.5), max_accel=(5.0, 9.0, 8.0), max_jerk=(25.0, 35.0, 12.0))
+    keys = dict(state_weight="state_weight", input_weight="input_weight", smooth_input_weight="smooth_input_weight",
+                max_vel="max_velocity", max_accel="max_acceleration", max_jerk="max_jerk")
+    lines = ["mpc_12state_node:", "  ros__parameters:", "    debug: False", "    dt_pred: %r" % dt, "    mpc_window: %d" % N,
+             "    enable_control_smoothing: False", "    minimum_altitude: -1.0"]
+    for name, triple in vals.items():
+        for ax, v in zip(("xy", "z", "yaw"), triple):
+            lines.append("    %s_%s: %r" % (ax, keys[name], v))
+    path = tmp_path / "mpc_12state.yaml"
+    path.write_text("\n".join(lines) + "\n")
+    mpc = tg.MPC12STATE()
+    prm = configure_mpc12(mpc, str(path))
+    assert prm["_rejected"] == [] and mpc.initMPCProblem()
+    x0, ref = oracle.synth_mpc12(67, N, dt, 3)
+    eng = tg.BatchedMPC12(tg.mpc12_params(N=N, dt=dt, **vals))
+    oracle.match_engine(eng)
+    s = {k: oracle.fixed_rho_settings(eng.rho(k), warm_start=0) for k in ("xy", "z", "yaw")}
+    chain = oracle.Mpc12(oracle.mpc12_params(N=N, dt=dt, **vals), s)
+    done = 0
+    for b in range(3):
+        ro = chain.loop(x0[b], ref[b])
+        assert mpc.setCurrentState(x0[b]) and mpc.setReferenceTraj(ref[b])
+        assert mpc.mpcLoop() == bool(ro["ok"])
+        if not ro["ok"]:
+            continue
+        done += 1
+        X, U = mpc.getOptimalStateTraj(), mpc.getOptimalControlTraj()
+        assert np.abs(X - ro["X"]).max() < 1e-9 and np.abs(U - ro["U"]).max() < 1e-9
+        msg = from_mpc12(X, U, N, dt, start_t=3.25, frame_id="map")
+        assert len(msg.states) == N and len(msg.pose_path) == N + 1
+        for i, st in enumerate(msg.states):           # states[i] = horizon state i + 1 and the jerk of step i
+            j = 12 * (i + 1)
+            assert abs(st.time_from_start - (i + 1) * dt) < 1e-15
+            assert abs(st.position.y - ro["X"][j + 3]) < 1e-9 and abs(st.velocity.z - ro["X"][j + 7]) < 1e-9
+            assert abs(st.acceleration.x - ro["X"][j + 2]) < 1e-9 and abs(st.jerk.z - ro["U"][4 * i + 2]) < 1e-9
+            assert abs(st.yaw - ro["X"][j + 9]) < 1e-9 and abs(st.yaw_jerk - ro["U"][4 * i + 3]) < 1e-9
+        last = 12 * N                                  # the command is the LAST horizon state (:476)
+        assert abs(msg.command.translation.x - ro["X"][last]) < 1e-9
+        assert abs(msg.command.rotation.z - np.sin(0.5 * ro["X"][last + 9])) < 1e-9
+        assert abs(msg.pose_path[0].position.z - ro["X"][6]) < 1e-9 and abs(msg.pose_path[2].stamp - (3.25 + 2 * dt)) < 1e-12
+    assert done >= 2
+
+
 # ---------------------------------------------------------------- batches in flight on several handles
 def test_handles_on_their_own_streams_overlap_without_interfering(tg):
     """What the benchmark's small-batch workloads do: consecutive batches go to different handles,
