@@ -21,6 +21,7 @@
  */
 #include "mpc_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -770,6 +771,7 @@ int osqp_solve(osqp_work *w)
     w->rho_updates = 0;
     if (w->nphase > 1) apply_phase(w, 0);
     int iter, checked = 0;
+    const int trace = getenv("ORACLE_TRACE") != NULL;      /* debugging aid: residuals and thresholds at every check */
     for (iter = 1; iter <= w->s.max_iter; iter++) {
         memcpy(w->x_prev, w->x, sizeof(double) * n);
         memcpy(w->z_prev, w->z, sizeof(double) * m);
@@ -812,6 +814,9 @@ int osqp_solve(osqp_work *w)
             /* with the finer schedule the infeasibility certificates are tested only where OSQP's
                own schedule has a check */
             int full = w->s.check_fine <= 0 || iter % w->s.check_termination == 0 || iter == w->s.max_iter;
+            if (trace)
+                fprintf(stderr, "oracle check at %d (phase %d): pri %.17g of %.17g, dua %.17g of %.17g\n", iter, w->phase,
+                        w->pri_res, eps_prim(w, w->s.eps_abs, w->s.eps_rel), w->dua_res, eps_dual(w, w->s.eps_abs, w->s.eps_rel));
             if (check_termination_ex(w, 0, full)) break;
             /* step-size schedule: still running at the first check at or after a phase's start */
             if (w->nphase > 1 && iter < w->s.max_iter) {
