@@ -230,6 +230,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     constexpr double s3 = 0.86602540378443864676, s2 = 0.70710678118654752440; // sqrt(3)/2, sqrt(2)/2
 
     for (int j = tid; j < CTAB; j += kThreads) lds[j] = 0.0;
+    if (a.zero_counts != nullptr && blockIdx.x == 0 && tid < 2) a.zero_counts[tid] = 0;
     if (tid < NAX * S) {
         const int ax = tid / S, k = tid % S;
         lds[CTAB + tid * 3 + 0] = P.rho_box[ax][k];

@@ -118,9 +118,12 @@ struct BatchArgs {
     // next_list / next_count (device, may be null): where this launch appends the instances it
     // hands over to the next phase; their iterates go to `warm` (x, z, y with y unscaled, so that
     // the rows mean the same under every operator).
+    // zero_counts (device, may be null): two hand-over counters that no launch of this solve uses; the
+    // first launch clears them for the next solve of the handle, which saves a memset per solve.
     const int *count;
     int *next_list;
     int *next_count;
+    int *zero_counts;
 };
 
 // dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static share (the block-wide vote helpers keep a few words there)

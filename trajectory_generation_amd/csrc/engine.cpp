@@ -105,7 +105,7 @@ struct DevStage {
     std::vector<std::unique_ptr<DevStage>> later;
     int phase_iters[2] = {-1, -1};
     double phase_scale[2][4] = {{1, 1, 1, 1}, {1, 1, 1, 1}};
-    int *d_plist[2] = {nullptr, nullptr}; int plist_cap = 0; int *d_pcount = nullptr;
+    int *d_plist[2] = {nullptr, nullptr}; int plist_cap = 0; int *d_pcount = nullptr; int pcount_set = 0;
 
     int init(const StageModel &mdl, const tg_solver_opts &o, double rho)
     {
@@ -448,7 +448,13 @@ struct DevStage {
     // hand-over lists of the step-size schedule: two lists of instance numbers and a counter per phase boundary
     int ensure_plist(int B)
     {
-        if (!d_pcount) HIP_TRY(hipMalloc((void **)&d_pcount, 2 * sizeof(int)));
+        // two sets of two counters: a solve counts in one set and its first launch clears the other
+        // for the solve after it (stream order makes that safe; solves of one handle follow each other)
+        if (!d_pcount) {
+            HIP_TRY(hipMalloc((void **)&d_pcount, 4 * sizeof(int)));
+            HIP_TRY(hipMemset(d_pcount, 0, 4 * sizeof(int)));
+            pcount_set = 0;
+        }
         if (B <= plist_cap) return TG_OK;
         hipFree(d_plist[0]); hipFree(d_plist[1]); d_plist[0] = d_plist[1] = nullptr; plist_cap = 0;
         const int cap = (B + 255) / 256 * 256;
@@ -490,7 +496,7 @@ struct DevStage {
         }
         a.list = nullptr; a.order_list = nullptr; a.order_score = nullptr; a.order_hdr = nullptr;
         a.grid_cap = grid_cap;
-        a.count = nullptr; a.next_list = nullptr; a.next_count = nullptr;
+        a.count = nullptr; a.next_list = nullptr; a.next_count = nullptr; a.zero_counts = nullptr;
         // The step-size schedule: phase p ends at the first check at or after phase_iters[p]; an
         // end at or beyond max_iter never comes.  Without allocation there is one phase only.
         // Two boundaries that fall on the same check leave the operator between them unused.
@@ -517,7 +523,6 @@ struct DevStage {
             if (rc) return rc;
             if ((rc = ensure_plist(a.B))) return rc;
             a.ldw = warm_cap; a.warm = d_warm;
-            HIP_TRY(hipMemsetAsync(d_pcount, 0, 2 * sizeof(int), s));
         }
         const char *why = "";
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -550,6 +555,7 @@ struct DevStage {
                     ap.order_list = nullptr; ap.order_score = nullptr; ap.order_hdr = nullptr;
                 }
                 if (p + 1 < nphase) { ap.next_list = plist[p & 1]; ap.next_count = pcount + p; }
+                ap.zero_counts = (p == 0 && nphase > 1) ? d_pcount + 2 * (pcount_set ^ 1) : nullptr;
                 hipError_t e = launch_admm(d, ap, st, &why);
                 if (e != hipSuccess)
                     return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
@@ -557,11 +563,16 @@ struct DevStage {
             }
             return TG_OK;
         };
-        const int crc = chain(a, d_plist, d_pcount, s);
+        const int crc = chain(a, d_plist, d_pcount + 2 * pcount_set, s);
         if (crc != TG_OK) {
             if (timing) { hipEventDestroy(e0); hipEventDestroy(e1); }
+            if (nphase > 1) {       // part of the chain may have run: both counter sets start over
+                hipStreamSynchronize(s);
+                hipMemset(d_pcount, 0, 4 * sizeof(int));
+            }
             return crc;
         }
+        if (nphase > 1) pcount_set ^= 1;
         if (timing) {
             if (hipEventRecord(e1, s) != hipSuccess) {
                 hipEventDestroy(e0); hipEventDestroy(e1);

@@ -214,10 +214,19 @@ inline void default_phases(const StageModel &mdl, int iters[2], double scale[2][
         for (int k = 0; k < 4; k++) scale[p][k] = 1.0;
     }
     if (mdl.family == TG_FAM_6DOF) {
-        // (short horizons have no such tail: N = 20 needs 75 iterations at eps 1e-9 and at most 225 with
-        // or without a schedule, and two continuation launches that find nothing would cost a batch of
-        // 4096 a tenth of its 0.12 ms)
-        if (mdl.N <= 30) return;
+        if (mdl.N <= 30) {
+            // Short horizons have no such tail in a single solve (N = 20 needs 75 iterations at eps 1e-9,
+            // 125 at most), but a closed loop has: a vehicle that the plant carries a few centimetres
+            // below the altitude floor poses a problem that is infeasible by that much, and at a fixed
+            // step 4000 iterations neither solve nor certify it (8192 vehicles x 500 steps: 0.002 % of the
+            // solves, which made a step 1.14 ms instead of 0.21).  One later operator, far out, ends those
+            // after 175-275 iterations; an earlier boundary (100) would slow tight single solves down
+            // (slowest of 2048 at eps 1e-9: 350 against 125), and every boundary costs a batch of 4096 an
+            // empty continuation launch (6 us of 117).
+            iters[0] = 150; scale[0][0] = 64.0;
+            scale[1][0] = 64.0;
+            return;
+        }
         iters[0] = 100; scale[0][0] = 8.0;
         iters[1] = 200; scale[1][0] = 64.0;
     } else if (mdl.family == TG_FAM_XY) {
