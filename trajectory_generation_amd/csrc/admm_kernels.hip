@@ -138,6 +138,13 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // entries of a.list as the previous phase handed over; read where it is needed (start and
     // refills) rather than kept in a register across the iterations
     auto batch_size = [&]() __attribute__((always_inline)) -> int { return a.count ? __builtin_amdgcn_readfirstlane(*a.count) : a.B; };
+    // A continuation launch is sized for the whole batch but usually takes a few instances or none:
+    // a workgroup whose start tickets lie past the list and that could take nothing from the queue
+    // leaves before any set-up.
+    if (a.count != nullptr) {
+        const int nb0 = batch_size();
+        if ((int)blockIdx.x * kTileDev >= nb0 && (a.queue == nullptr || a.queue_base >= nb0)) return;
+    }
     const int N = P.N, N1 = P.N + 1, ncell = NAX * N1;
     const int n_int = P.n_int, nb = P.nb, ks = P.ks, nrb = P.nrb;
     // Cell cc of thread group g: linear cell index ax * (N+1) + st, or ncell for an unused slot.
