@@ -123,8 +123,8 @@ typedef struct {
      * relies on.  Decided per instance, at the check; instances that move are gathered and solved
      * together, so the operator stays shared.  phase_scale[p] multiplies the first operator's
      * rho_scale for phase p + 1.  phase_iters: 0 = the built-in choice (100 and 200 iterations;
-     * 6-DOF with N > 30: the step on the position rows x 8 and x 64 (shorter horizons: none),
-     * 12-state Z and yaw stages: on the speed
+     * 6-DOF with N > 30: the step on the position rows x 8 and x 64; shorter horizons: one later
+     * operator, position rows x 64 from iteration 150; 12-state Z and yaw stages: on the speed
      * rows x 10 and x 100, XY stage: on the acceleration rows x 3 and x 10),
      * < 0 = no such phase; phase_scale entries of 0 = built-in.  Frozen at create (the operators
      * are built there); tg_*_set_opts ignores both.  The entry point that allocates nothing runs
