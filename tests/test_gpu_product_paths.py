@@ -562,6 +562,20 @@ def test_residuals_and_option_getters(tg, oracle):
     for k in ("z", "xy", "yaw"):
         a, b = e12.last_residuals(k, 8)
         assert np.isfinite(a).all() and np.isfinite(b).all() and (a >= 0).all()
+    # get -> change a run-time setting -> set, from any stage's options (their step sizes differ and are
+    # frozen: set_opts takes the run-time settings and leaves rho / rho_scale / the schedule alone)
+    for k in ("yaw", "xy"):
+        o12 = e12.get_opts(k)
+        o12.max_iter = 1500 if k == "yaw" else 2500
+        e12.set_opts(o12)
+        assert [e12.get_opts(j).max_iter for j in ("xy", "z", "yaw")] == [o12.max_iter] * 3
+        assert [e12.get_opts(j).rho for j in ("xy", "z", "yaw")] == [e12.rho(j) for j in ("xy", "z", "yaw")]
+    # the entry point that allocates nothing keeps no residual record: asking for one is an error, not stale numbers
+    buf = e12.alloc(8)
+    _to_dev(buf, x12, r12)
+    e12.solve_static(buf)
+    with pytest.raises(capi.TgError):
+        e12.last_residuals("z", 8)
 
 
 def test_yaml_to_engine_to_messages(tg, oracle, tmp_path):
