@@ -111,10 +111,10 @@ typedef struct {
     /* Order in which a grid whose slots are refilled (grid_cap above) takes the instances of the
      * batch.  1: the sixteenth of the batch whose reference strays farthest from where the initial
      * state coasts to is taken first -- those instances tend to need the most iterations, and
-     * started last they would leave the GPU waiting for them; -1: batch order; 0: where it pays,
-     * which is on handles without a step-size schedule (phase_iters below: with one, an instance
-     * leaves the first launch after phase_iters[0] iterations wherever it started).  An instance's
-     * result does not depend on it. */
+     * started last they would leave the GPU waiting for them; -1: batch order; 0: where it pays:
+     * on handles without a step-size schedule, and with one (phase_iters below: an instance then
+     * leaves the first launch after phase_iters[0] iterations wherever it started) for batches of
+     * at most 49152 instances.  An instance's result does not depend on it. */
     int    hard_first;
     /* Step-size schedule, in place of OSQP's run-time rho adaptation.  A handle holds up to three
      * factorised operators; an instance that is still running at the first termination check at

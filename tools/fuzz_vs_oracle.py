@@ -286,7 +286,30 @@ for trial in range(TRIALS):
         O.match_engine(eng)
         s = {k: O.fixed_rho_settings(eng.rho(k), warm_start=0, **o) for k in ("xy", "z", "yaw")}
         ro = O.mpc12_batch(O.mpc12_params(**kw12), s, x, ref)
-        report("12st ", trial, desc, r, ro, (ro["status"] == 1).all(1), 1e-7)
+        before = bad
+        okc = (ro["status"] == 1).all(1)
+        report("12st ", trial, desc, r, ro, okc, 1e-7)
+        if bad > before and okc.any() and (r["status"] == ro["status"]).all() and (r["iters"][:, :2] == ro["iters"][:, :2]).all():
+            # Only the yaw columns apart?  yaw_ref = atan2(target - plan) (mpc_12state.cpp:544-548) of a vector
+            # of next to no length turns rounding-level differences of the XY solutions into different yaw
+            # problems.  Then the engine's yaw stage, given the oracle's XY solution, must reproduce the
+            # oracle's yaw stage: if it does, the draw shows that sensitivity and nothing else.
+            dX = np.abs(r["X"][okc] - ro["X"][okc]).reshape(int(okc.sum()), -1, 12)
+            if dX[:, :, :9].max() < 1e-9 * max(1.0, np.abs(ro["X"][okc]).max()):
+                buf = eng.alloc(B)
+                buf["x0"][:, :B] = torch.from_numpy(np.ascontiguousarray(x.T)).cuda()
+                buf["ref"][:, :B] = torch.from_numpy(np.ascontiguousarray(ref.T)).cuda()
+                buf["X"][:, :B] = torch.from_numpy(np.ascontiguousarray(np.where(okc[:, None], ro["X"], 0.0).T)).cuda()
+                eng.solve_stage("yaw", buf)
+                torch.cuda.synchronize()
+                Xy = buf["X"][:, :B].cpu().numpy().T
+                st2, it2 = buf["status"][2, :B].cpu().numpy(), buf["iters"][2, :B].cpu().numpy()
+                same = (st2[okc] == ro["status"][okc, 2]).all() and (it2[okc] == ro["iters"][okc, 2]).all()
+                dy = float(np.abs(Xy[okc] - ro["X"][okc]).max() / max(1.0, np.abs(ro["X"][okc]).max()))
+                print("      yaw stage on the oracle's XY solution: statuses and iterations equal %s, d %.1e" % (same, dy), flush=True)
+                if same and dy < 1e-7:
+                    bad -= 1
+                    print("      -> sensitivity of the yaw reference to the last bits of the XY solution (not counted)", flush=True)
         if DUMP and (not os.environ.get("FUZZ_DUMP_TRIALS") or str(trial) in os.environ["FUZZ_DUMP_TRIALS"].split(",")):
             import json
             os.makedirs(DUMP, exist_ok=True)

@@ -509,11 +509,12 @@ struct DevStage {
                 bound[nphase - 1] = b; oper[nphase] = p + 1; nphase++;
             }
         }
-        // Likely slow instances first (hard_first): 1 always, 0 where it pays -- without a schedule.  With
-        // one the slow instances leave the first launch after phase_iters[0] iterations wherever they
-        // started, and ordering the batch costs more than it saves (N = 50, 262144 instances: 14.5
-        // against 14.2 ms).
-        if (!no_alloc && grid_cap >= 0 && (hard_first > 0 || (hard_first == 0 && nphase == 1)) && a.B > 16 * 256) {   // smaller batches never go through the queue
+        // Likely slow instances first (hard_first): 1 always, 0 where it pays.  With a schedule the slow
+        // instances leave the first launch after phase_iters[0] iterations wherever they started, and
+        // ordering a large batch costs more than it saves (N = 50, 262144 instances: 14.5 against
+        // 14.2 ms); a batch of a few rounds of the grid still gains (32768: 2.65 against 2.75 ms).
+        const bool pays = nphase == 1 || a.B <= 48 * 1024;
+        if (!no_alloc && grid_cap >= 0 && (hard_first > 0 || (hard_first == 0 && pays)) && a.B > 16 * 256) {   // smaller batches never go through the queue
             int rc = ensure_order(a.B);
             if (rc) return rc;
             a.order_list = d_olist; a.order_score = d_oscore; a.order_hdr = d_ohdr;
