@@ -112,9 +112,10 @@ typedef struct {
      * batch.  1: the sixteenth of the batch whose reference strays farthest from where the initial
      * state coasts to is taken first -- those instances tend to need the most iterations, and
      * started last they would leave the GPU waiting for them; -1: batch order; 0: where it pays:
-     * on handles without a step-size schedule, and with one (phase_iters below: an instance then
-     * leaves the first launch after phase_iters[0] iterations wherever it started) for batches of
-     * at most 49152 instances.  An instance's result does not depend on it. */
+     * horizons longer than 30, on handles without a step-size schedule, and with one (phase_iters
+     * below: an instance then leaves the first launch after phase_iters[0] iterations wherever it
+     * started) for batches of at most 49152 instances.  An instance's result does not depend on
+     * it. */
     int    hard_first;
     /* Step-size schedule, in place of OSQP's run-time rho adaptation.  A handle holds up to three
      * factorised operators; an instance that is still running at the first termination check at

@@ -747,7 +747,7 @@ def test_handles_on_their_own_streams_overlap_without_interfering(tg):
 # ---------------------------------------------------------------- order in which a refilled grid takes the batch
 def test_hard_first_order_changes_nothing_but_the_order(tg):
     """A refilled grid can take the sixteenth of the batch that is likely to need the most iterations
-    first (tg_solver_opts.hard_first = 1; the default where there is no step-size schedule).
+    first (tg_solver_opts.hard_first = 1; by default only where it pays: long horizons, see tg_mpc.h).
     Statuses, iteration counts and solutions equal those in batch order bit for bit, with an
     infeasible instance in the batch, with and without a schedule; and the instances that needed
     the most iterations are indeed among those the ordering puts first."""
