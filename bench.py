@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--no-schedule", action="store_true", help="first operator only: no step-size schedule (phase_iters = -1)")
     ap.add_argument("--phase-iters", default="", help="two iteration counts 'a,b' for the step-size schedule in place of the built-in ones")
     ap.add_argument("--phase-scale", default="", help="class multipliers 'p,v,a,i;p,v,a,i' of the schedule's operators (0 = built-in)")
+    ap.add_argument("--overlap", action="store_true", help="12-state chain: the yaw stage of the vehicles done with XY runs beside the XY stage's continuation launches (default: stages strictly in turn)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-target-leg", action="store_true", help="skip the second leg (rate at the tolerance that lands within 1e-4 of a converged run)")
     ap.add_argument("--no-check-fine", action="store_true", help="skip the second figure with the finer schedule of checks (check_fine_5)")
@@ -318,6 +319,8 @@ def main():
         sched = dict(phase_iters=tuple(int(v) for v in args.phase_iters.split(",")))
     if args.phase_scale:
         sched["phase_scale"] = tuple(tuple(float(v) for v in part.split(",")) for part in args.phase_scale.split(";"))
+    if args.overlap:
+        sched["overlap"] = 1
     opts = tg.make_opts(eps_abs=args.eps, eps_rel=args.eps, max_iter=args.max_iter, check_termination=args.check,
                         check_fine=args.check_fine, grid_cap=args.grid_cap, lowrank=args.lowrank, hard_first=args.hard_first, **sched)
     closed = args.workload.startswith("rollout")
@@ -480,6 +483,8 @@ def main():
         phases = [tg.phase_launches(eng.get_opts(), Bh)]
     else:
         phases = [tg.phase_launches(eng.get_opts(k), Bh) for k in ("z", "xy", "yaw")]
+        if phases[1] > 1 and int(eng.get_opts("xy").overlap) > 0:
+            phases[2] *= 2            # the yaw stage runs twice: vehicles done with XY early, then the late finishers
     launches_per_step = sum(phases) * (depth if closed else 1)
     if model == "6dof":
         info = [eng.kernel_info()]

@@ -132,6 +132,16 @@ typedef struct {
      * the first operator only. */
     int    phase_iters[2];
     double phase_scale[2][4];
+    /* 12-state chain: 1 = when the XY stage has a step-size schedule, the yaw stage of the vehicles
+     * whose XY problem the first XY launch solved runs on a second stream of the handle beside the
+     * XY stage's continuation launches, and the vehicles those solve get their yaw stage
+     * afterwards; 0 (default) = the three stages strictly one after the other.  Results are the
+     * same bit for bit; the work is complete when the caller's stream is.  It shortens a batch
+     * that runs alone (4096 vehicles, N = 20: 1.95 against 2.15 ms) and costs throughput when
+     * several handles keep batches in flight (their streams then outnumber the hardware queues).
+     * Frozen at create; ignored by the 6-DOF handles and by the entry point that allocates
+     * nothing. */
+    int    overlap;
 } tg_solver_opts;
 
 void tg_default_opts(tg_solver_opts *o);

@@ -915,3 +915,44 @@ def test_closed_loop_6dof_stragglers_end_early_with_the_built_in_schedule(tg):
     print("closed loop 6-DOF 8192 x %d, (slowest solve, solves that ran to max_iter): %s" % (steps, worst))
     assert worst["schedule"][0] <= 500 and worst["schedule"][1] == 0, worst
     assert worst["one operator"][0] == 4000 and worst["one operator"][1] > 0, worst     # what the later operator is there for
+
+
+@pytest.mark.parametrize("warm", [False, True])
+def test_12state_stage_overlap_is_bit_identical(tg, warm):
+    """The 12-state chain with the yaw stage of the early XY finishers running beside the XY stage's
+    continuation launches (tg_solver_opts.overlap = 1) against the stages strictly in turn (0, the
+    default): statuses, iteration counts, X and U equal bit for bit -- on the benchmark batch (with its
+    vehicle whose XY problem is infeasible and is certified in the third XY launch), with sentinel-filled
+    outputs so that untouched columns show, over several warm-started closed-loop steps, and with an XY
+    schedule early enough that many vehicles finish XY late and take the second yaw pass."""
+    import torch
+    from trajectory_generation_amd import synth
+    N, B = 20, 4096
+    x0, ref = synth.mpc12(SEED + 3, N, 0.1, B)
+    for kw in ({}, dict(phase_iters=(25, 50))):
+        res = []
+        for ov in (1, 0):
+            eng = tg.BatchedMPC12(tg.mpc12_params(N=N), tg.make_opts(overlap=ov, **kw))
+            assert int(eng.get_opts("xy").overlap) == ov
+            buf = eng.alloc(B)
+            _to_dev(buf, x0, ref)
+            eng.reset_warm()
+            buf["X"].fill_(-3.0); buf["U"].fill_(-3.0); buf["status"].fill_(77); buf["iters"].fill_(-1)
+            snaps = []
+            for k in range(4 if warm else 1):
+                eng.solve(buf, warm=warm)
+                snaps.append({n: buf[n].clone() for n in ("X", "U", "status", "iters")})
+                if warm:
+                    eng.plant_step(buf); eng.ref_shift(buf)
+                    snaps[-1]["x0"] = buf["x0"].clone()
+            torch.cuda.synchronize()
+            res.append(snaps)
+        for a, b in zip(*res):
+            for n in a:
+                assert torch.equal(a[n], b[n]), (kw, n)
+        st = res[0][0]["status"][:, :B]
+        late = int(((res[0][0]["iters"][1, :B] > (25 if kw else 100)) & (st[1] == 1)).sum())
+        assert int((st == 77).sum()) == 0 and int((st[2] == 1).sum()) > 0.99 * B
+        if kw:
+            assert late > 100, late           # the second yaw pass had real work
+        print("overlap %s warm %s: %d vehicles finished XY in a continuation launch" % (kw or "built-in schedule", warm, late))

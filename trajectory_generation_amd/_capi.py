@@ -43,7 +43,7 @@ class SolverOpts(C.Structure):
                 ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("max_iter", C.c_int),
                 ("check_termination", C.c_int), ("rho_scale", C.c_double * 4),
                 ("eps_prim_inf", C.c_double), ("check_fine", C.c_int), ("grid_cap", C.c_int), ("lowrank", C.c_int), ("hard_first", C.c_int),
-                ("phase_iters", C.c_int * 2), ("phase_scale", (C.c_double * 4) * 2)]
+                ("phase_iters", C.c_int * 2), ("phase_scale", (C.c_double * 4) * 2), ("overlap", C.c_int)]
 
 
 # every symbol include/tg_mpc.h declares: name -> (restype, argtypes)

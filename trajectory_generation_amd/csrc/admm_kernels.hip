@@ -141,6 +141,9 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     // A continuation launch is sized for the whole batch but usually takes a few instances or none:
     // a workgroup whose start tickets lie past the list and that could take nothing from the queue
     // leaves before any set-up.
+    // (the first launch of a solve clears the hand-over counters of the solve after it; it may itself
+    // be a launch over a list that turns out empty, so this comes first)
+    if (a.zero_counts != nullptr && blockIdx.x == 0 && tid < 2) a.zero_counts[tid] = 0;
     if (a.count != nullptr) {
         const int nb0 = batch_size();
         if ((int)blockIdx.x * kTileDev >= nb0 && (a.queue == nullptr || a.queue_base >= nb0)) return;
@@ -237,7 +240,6 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
     constexpr double s3 = 0.86602540378443864676, s2 = 0.70710678118654752440; // sqrt(3)/2, sqrt(2)/2
 
     for (int j = tid; j < CTAB; j += kThreads) lds[j] = 0.0;
-    if (a.zero_counts != nullptr && blockIdx.x == 0 && tid < 2) a.zero_counts[tid] = 0;
     if (tid < NAX * S) {
         const int ax = tid / S, k = tid % S;
         lds[CTAB + tid * 3 + 0] = P.rho_box[ax][k];
@@ -1392,7 +1394,12 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     if (a.iters) a.iters[inst] = local;
                     if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.res_ld + inst] = m_rd; }
                 }
-                if (g == 0 && pexit) a.next_list[atomicAdd(a.next_count, 1)] = inst;
+                if (g == 0 && pexit) {
+                    a.next_list[atomicAdd(a.next_count, 1)] = inst;
+                    if (a.status) a.status[inst] = TG_DEV_UNSOLVED;   // not decided yet: a later launch of this solve will say
+                }
+                if (g == 0 && fin && verdict == TG_DEV_SOLVED && a.done_list != nullptr)
+                    a.done_list[atomicAdd(a.done_count, 1)] = inst;
                 if (a.warm_out || pexit) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
@@ -1610,8 +1617,10 @@ __global__ __launch_bounds__(256) void yaw_ref_kernel(int B, int ld, int N,
 __global__ __launch_bounds__(256) void merge12_kernel(int B, int ld, int rowsX, int rowsU, int rows_per_block,
                                                        const double *__restrict__ Xs, const double *__restrict__ Us,
                                                        const int *__restrict__ status,
-                                                       double *__restrict__ X, double *__restrict__ U)
+                                                       double *__restrict__ X, double *__restrict__ U, int *clear)
 {
+    // (clear: a counter of the chain that has been consumed by now and starts the next chain at zero)
+    if (clear != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear = 0;
     const int inst = blockIdx.x * blockDim.x + threadIdx.x;
     if (inst >= B) return;
     const bool ok = status[inst] == TG_DEV_SOLVED && status[(size_t)ld + inst] == TG_DEV_SOLVED &&
@@ -2070,11 +2079,11 @@ hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double 
 }
 
 hipError_t launch_merge12(int B, int ld, int N, const double *Xs, const double *Us, const int *status, double *X,
-                          double *U, hipStream_t s)
+                          double *U, int *clear, hipStream_t s)
 {
     const int rowsX = 12 * (N + 1), rowsU = 4 * N, rpb = 32;
     dim3 grid((B + 255) / 256, (rowsX + rowsU + rpb - 1) / rpb);
-    hipLaunchKernelGGL(merge12_kernel, grid, dim3(256), 0, s, B, ld, rowsX, rowsU, rpb, Xs, Us, status, X, U);
+    hipLaunchKernelGGL(merge12_kernel, grid, dim3(256), 0, s, B, ld, rowsX, rowsU, rpb, Xs, Us, status, X, U, clear);
     return hipGetLastError();
 }
 

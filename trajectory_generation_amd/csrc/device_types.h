@@ -124,6 +124,10 @@ struct BatchArgs {
     int *next_list;
     int *next_count;
     int *zero_counts;
+    // done_list / done_count (device, may be null): a launch appends the instances it ends as
+    // solved (the 12-state chain starts the next stage for the late finishers of this one from it).
+    int *done_list;
+    int *done_count;
 };
 
 // dynamic LDS a workgroup may ask for: the CU's 160 KiB less the kernel's static share (the block-wide vote helpers keep a few words there)

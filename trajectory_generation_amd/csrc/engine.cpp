@@ -6,6 +6,7 @@
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -27,7 +28,7 @@ hipError_t launch_ref_shift(int B, int ld, int nx, int N, double *ref, hipStream
 hipError_t launch_yaw_ref(int B, int ld, int N, const double *ref, const double *X, double *yaw_ref,
                           hipStream_t s);
 hipError_t launch_merge12(int B, int ld, int N, const double *Xs, const double *Us, const int *status, double *X,
-                          double *U, hipStream_t s);
+                          double *U, int *clear, hipStream_t s);
 hipError_t static_scratch_init(int dev);
 void *static_scratch_ptr(int dev);
 } // namespace tg
@@ -472,9 +473,32 @@ struct DevStage {
         res_cap = ld;
         return TG_OK;
     }
+    // What the 12-state chain adds to a stage's solve when it overlaps two stages.
+    struct SolveExtra {
+        const int *first_list = nullptr, *first_count = nullptr;   // the first launch takes this list instead of the batch
+        int *done_list = nullptr, *done_count = nullptr;           // launches after the first append what they solve
+        int warm_in = -1;                                          // >= 0: whether warm rows are read, decided by the caller
+        std::function<int()> after_first;                          // called when the first launch has been issued
+    };
+    // Phases a solve will run and the checks they end at (the step-size schedule: phase p ends at the
+    // first check at or after phase_iters[p]; an end at or beyond max_iter never comes; two boundaries
+    // that fall on the same check leave the operator between them unused).
+    int plan_phases(int bound[2], int oper[3]) const
+    {
+        int nphase = 1;
+        bound[0] = bound[1] = 0; oper[0] = oper[1] = oper[2] = 0;
+        for (int p = 0; p < (int)later.size(); p++) {
+            const int b = (phase_iters[p] + dev.check - 1) / dev.check * dev.check;
+            if (b >= dev.max_iter) break;
+            if (nphase > 1 && b <= bound[nphase - 2]) { oper[nphase - 1] = p + 1; continue; }
+            bound[nphase - 1] = b; oper[nphase] = p + 1; nphase++;
+        }
+        return nphase;
+    }
+    bool warm_rows_valid(int B) const { return warm_valid && warm_B >= B; }
     // One batched ADMM solve of this stage.  no_alloc: the caller guarantees that nothing here may
     // allocate (no warm start, no residual record, no timing events; a.queue_mem is the caller's).
-    int solve(BatchArgs a, int warm, hipStream_t s, bool no_alloc = false)
+    int solve(BatchArgs a, int warm, hipStream_t s, bool no_alloc = false, const SolveExtra *ex = nullptr)
     {
         a.warm_in = 0; a.warm_out = 0; a.ldw = 0;
         a.warm = nullptr;
@@ -484,7 +508,7 @@ struct DevStage {
             if (rc) return rc;
             a.ldw = warm_cap;
             a.warm = d_warm;
-            a.warm_in = (warm_valid && warm_B >= a.B) ? 1 : 0;
+            a.warm_in = (ex && ex->warm_in >= 0) ? ex->warm_in : (warm_rows_valid(a.B) ? 1 : 0);
             a.warm_out = 1;
         }
         a.res = nullptr; a.res_ld = 0;
@@ -497,18 +521,10 @@ struct DevStage {
         a.list = nullptr; a.order_list = nullptr; a.order_score = nullptr; a.order_hdr = nullptr;
         a.grid_cap = grid_cap;
         a.count = nullptr; a.next_list = nullptr; a.next_count = nullptr; a.zero_counts = nullptr;
-        // The step-size schedule: phase p ends at the first check at or after phase_iters[p]; an
-        // end at or beyond max_iter never comes.  Without allocation there is one phase only.
-        // Two boundaries that fall on the same check leave the operator between them unused.
+        a.done_list = nullptr; a.done_count = nullptr;
+        // The step-size schedule.  Without allocation there is one phase only.
         int bound[2] = {0, 0}, oper[3] = {0, 0, 0}, nphase = 1;
-        if (!no_alloc) {
-            for (int p = 0; p < (int)later.size(); p++) {
-                const int b = (phase_iters[p] + dev.check - 1) / dev.check * dev.check;
-                if (b >= dev.max_iter) break;
-                if (nphase > 1 && b <= bound[nphase - 2]) { oper[nphase - 1] = p + 1; continue; }
-                bound[nphase - 1] = b; oper[nphase] = p + 1; nphase++;
-            }
-        }
+        if (!no_alloc) nphase = plan_phases(bound, oper);
         // Likely slow instances first (hard_first): 1 always, 0 where it pays.  With a schedule the slow
         // instances leave the first launch after phase_iters[0] iterations wherever they started, and
         // ordering a large batch costs more than it saves (N = 50, 262144 instances: 14.5 against
@@ -559,10 +575,18 @@ struct DevStage {
                 }
                 if (p + 1 < nphase) { ap.next_list = plist[p & 1]; ap.next_count = pcount + p; }
                 ap.zero_counts = (p == 0 && nphase > 1) ? d_pcount + 2 * (pcount_set ^ 1) : nullptr;
+                if (ex) {
+                    if (p == 0 && ex->first_count) { ap.count = ex->first_count; ap.list = ex->first_list; }
+                    if (p > 0) { ap.done_list = ex->done_list; ap.done_count = ex->done_count; }
+                }
                 hipError_t e = launch_admm(d, ap, st, &why);
                 if (e != hipSuccess)
                     return fail(e == hipErrorInvalidValue ? TG_E_ARG : TG_E_HIP,
                                 std::string("admm launch: ") + (why[0] ? why : hipGetErrorString(e)));
+                if (p == 0 && ex && ex->after_first) {
+                    const int rc = ex->after_first();
+                    if (rc != TG_OK) return rc;
+                }
             }
             return TG_OK;
         };
@@ -699,6 +723,7 @@ void tg_default_opts(tg_solver_opts *o)
         o->phase_iters[p] = 0;
         for (int k = 0; k < 4; k++) o->phase_scale[p][k] = 0.0;
     }
+    o->overlap = 0;
 }
 const char *tg_last_error(void) { return g_err.c_str(); }
 int tg_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
@@ -951,6 +976,21 @@ struct tg_mpc12 {
     HostStaging hs;
     // xy_max [6N] | mixed_max [6N] | yaw_ref [N+1] | stage status (2 rows) | Xs [12(N+1)] | Us [4N]
     double *d_inter = nullptr; int inter_ld = 0;
+    // Overlap of the XY stage's continuation launches with the yaw stage of the vehicles whose XY
+    // problem the first launch solved: a second stream, two events, and [gate: cap ints | late
+    // list: cap ints | late count] of device memory.
+    hipStream_t s2 = nullptr; hipEvent_t ev_xy0 = nullptr, ev_yaw = nullptr;
+    int *d_ovl = nullptr; int ovl_cap = 0;
+    int ensure_overlap(int ld)
+    {
+        if (ld <= ovl_cap) return TG_OK;
+        hipFree(d_ovl); d_ovl = nullptr; ovl_cap = 0;
+        const int cap = (ld + 63) / 64 * 64;
+        HIP_TRY(hipMalloc((void **)&d_ovl, ((size_t)2 * cap + 64) * sizeof(int)));
+        HIP_TRY(hipMemset(d_ovl + (size_t)2 * cap, 0, 64 * sizeof(int)));     // the count; every chain's merge clears it again
+        ovl_cap = cap;
+        return TG_OK;
+    }
     int ensure_inter(int ld)
     {
         if (ld <= inter_ld) return TG_OK;
@@ -1006,6 +1046,14 @@ int tg_mpc12_create(const tg_mpc12_params *p, const tg_solver_opts *o, const dou
         rc = h->st[fams[k]].init(model_12(*p, fams[k]), oo, rho);
         if (rc) { tg_mpc12_destroy(h); return rc; }
     }
+    if (oo.overlap > 0) {
+        if (hipStreamCreateWithFlags(&h->s2, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_xy0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_yaw, hipEventDisableTiming) != hipSuccess) {
+            tg_mpc12_destroy(h);
+            return fail(TG_E_HIP, "stream / events of the stage overlap could not be created");
+        }
+    }
     *out = h;
     return TG_OK;
 }
@@ -1014,8 +1062,11 @@ void tg_mpc12_destroy(tg_mpc12 *h)
 {
     if (!h) return;
     hipSetDevice(h->device);
+    if (h->s2) { hipStreamSynchronize(h->s2); hipStreamDestroy(h->s2); }
+    if (h->ev_xy0) hipEventDestroy(h->ev_xy0);
+    if (h->ev_yaw) hipEventDestroy(h->ev_yaw);
     for (int f = 1; f <= 3; f++) h->st[f].release();
-    h->hs.release(); hipFree(h->d_inter);
+    h->hs.release(); hipFree(h->d_inter); hipFree(h->d_ovl);
     delete h;
 }
 
@@ -1026,23 +1077,67 @@ void tg_mpc12_destroy(tg_mpc12 *h)
 // plan of its last successful call, Z rows included.
 static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int ld, const double *d_x0, const double *d_ref,
                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s,
-                       bool gated);
+                       bool gated, const DevStage::SolveExtra *ex = nullptr, const int *gate = nullptr);
 static int mpc12_chain(tg_mpc12 *h, const InterView &iv, int B, int ld, const double *d_x0, const double *d_ref,
                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s)
 {
     int rc;
     if ((rc = mpc12_stage(h, iv, TG_FAM_Z, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
-    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
-    HIP_TRY(launch_merge12(B, ld, h->p.N, iv.Xs, iv.Us, d_status, d_X, d_U, s));
+    int bound[2], oper[3];
+    const bool overlap = !iv.no_alloc && h->s2 != nullptr && h->st[TG_FAM_XY].plan_phases(bound, oper) > 1;
+    if (!overlap) {
+        if ((rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
+        if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true))) return rc;
+        HIP_TRY(launch_merge12(B, ld, h->p.N, iv.Xs, iv.Us, d_status, d_X, d_U, nullptr, s));
+        return TG_OK;
+    }
+    // The XY stage's first launch ends with most vehicles solved and a few handed over to its
+    // continuation launches, which a slow or infeasible problem can keep busy for a long time on a
+    // handful of CUs.  The yaw stage of the vehicles that are done does not wait for them: it runs
+    // on a second stream beside the continuation launches, and the vehicles those solve get their
+    // yaw stage afterwards, from the list the continuation launches write.  Every vehicle's three
+    // solves are what they are in the sequential chain, bit for bit.
+    if ((rc = h->ensure_overlap(ld))) return rc;
+    int *gate = h->d_ovl, *late = gate + h->ovl_cap, *late_n = late + h->ovl_cap;
+    const int yaw_warm_in = warm ? (h->st[TG_FAM_YAW].warm_rows_valid(B) ? 1 : 0) : -1;
+    DevStage::SolveExtra yx;           // both yaw passes read the warm rows, or neither
+    yx.warm_in = yaw_warm_in;
+    DevStage::SolveExtra xx;
+    xx.done_list = late; xx.done_count = late_n;
+    xx.after_first = [&]() -> int {
+        // the XY statuses as the first launch left them (handed-over vehicles: not attempted yet) gate the early yaw pass
+        HIP_TRY(hipMemcpyAsync(gate, d_status + (size_t)ld, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipEventRecord(h->ev_xy0, s));
+        HIP_TRY(hipStreamWaitEvent(h->s2, h->ev_xy0, 0));
+        const int r = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, h->s2, true, &yx, gate);
+        if (r != TG_OK) return r;
+        HIP_TRY(hipEventRecord(h->ev_yaw, h->s2));
+        return TG_OK;
+    };
+    rc = mpc12_stage(h, iv, TG_FAM_XY, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true, &xx);
+    if (rc != TG_OK) {                 // part of the chain may be in flight on the second stream: let it end, start the count over
+        hipStreamSynchronize(h->s2); hipStreamSynchronize(s);
+        hipMemset(late_n, 0, sizeof(int));
+        return rc;
+    }
+    HIP_TRY(hipStreamWaitEvent(s, h->ev_yaw, 0));
+    DevStage::SolveExtra lx = yx;
+    lx.first_list = late; lx.first_count = late_n;
+    if ((rc = mpc12_stage(h, iv, TG_FAM_YAW, B, ld, d_x0, d_ref, iv.Xs, iv.Us, d_status, d_iters, warm, s, true, &lx))) {
+        hipStreamSynchronize(s);
+        hipMemset(late_n, 0, sizeof(int));
+        return rc;
+    }
+    HIP_TRY(launch_merge12(B, ld, h->p.N, iv.Xs, iv.Us, d_status, d_X, d_U, late_n, s));
     return TG_OK;
 }
 
 // gated: instances whose upstream stage did not solve are skipped (status TG_UNSOLVED), as
-// MPC12STATE::mpcLoop returns at the first failing stage (mpc_12state.cpp:1374-1453)
+// MPC12STATE::mpcLoop returns at the first failing stage (mpc_12state.cpp:1374-1453); gate: the
+// statuses to go by, if not the upstream stage's row of d_status
 static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int ld, const double *d_x0, const double *d_ref,
                        double *d_X, double *d_U, int *d_status, int *d_iters, int warm, hipStream_t s,
-                       bool gated)
+                       bool gated, const DevStage::SolveExtra *ex, const int *gate)
 {
     const tg_mpc12_params &p = h->p;
     if (iv.ld != ld) return fail(TG_E_STATE, "leading dimension changed between stages");
@@ -1052,7 +1147,7 @@ static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int l
     const int slot = stage == TG_FAM_Z ? 0 : stage == TG_FAM_XY ? 1 : 2;
     a.status = d_status ? d_status + (size_t)slot * ld : nullptr;
     a.iters = d_iters ? d_iters + (size_t)slot * ld : nullptr;
-    if (gated && slot > 0 && d_status) a.gate = d_status + (size_t)(slot - 1) * ld;
+    if (gated && slot > 0 && d_status) a.gate = gate ? gate : d_status + (size_t)(slot - 1) * ld;
     if (stage == TG_FAM_XY) {
         // computeXYBounds from the Z solution already in X, then updateXYQP + solve
         HIP_TRY(launch_xy_bounds(B, ld, p.N, p.xy_max_vel, p.xy_max_accel, p.z_max_accel, d_X,
@@ -1063,7 +1158,7 @@ static int mpc12_stage(tg_mpc12 *h, const InterView &iv, int stage, int B, int l
         a.ref = iv.yaw_ref; a.ref_ld = iv.ld;
     }
     if (iv.no_alloc) a.queue_mem = h->st[stage].grid_cap >= 0 ? iv.queue[slot] : nullptr;
-    return h->st[stage].solve(a, warm, s, iv.no_alloc);
+    return h->st[stage].solve(a, warm, s, iv.no_alloc, ex);
 }
 
 static int mpc12_check(tg_mpc12 *h, int B, int ld, const void *a, const void *b, const void *c, const void *d)

@@ -17,7 +17,7 @@ def _torch():
 
 def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_iter=4000,
               check_termination=25, rho_scale=(0.0, 0.0, 0.0, 0.0), eps_prim_inf=1e-4, check_fine=0, grid_cap=0, lowrank=0, hard_first=0,
-              phase_iters=(0, 0), phase_scale=((0.0,) * 4, (0.0,) * 4)):
+              phase_iters=(0, 0), phase_scale=((0.0,) * 4, (0.0,) * 4), overlap=0):
     """rho <= 0 and rho_scale entries of 0 select the engine's built-in choices; rho_scale is
     (position, velocity, acceleration, input) multipliers of rho on the box rows;
     eps_prim_inf = 0 switches the primal infeasibility test off; check_fine > 0: after the first
@@ -26,10 +26,12 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
     16 instances); a smaller grid refills its instance slots from the rest of the batch;
     lowrank: K^-1 as diagonal tiles + low-rank rest (0: where it pays, 1: wherever possible, -1: dense).
     hard_first: a refilled grid takes the likely slow instances first (1), the batch in its order (-1),
-    or whichever pays (0: the former on handles without a step-size schedule).
+    or whichever pays (0: the former for horizons longer than 30; with a step-size schedule only for batches of at most 49152).
     phase_iters / phase_scale: the step-size schedule -- an instance still running at the first check
     at or after phase_iters[p] continues under an operator whose class multipliers are rho_scale x
-    phase_scale[p] (0: built-in choice, phase_iters < 0: no such phase)."""
+    phase_scale[p] (0: built-in choice, phase_iters < 0: no such phase).
+    overlap (12-state chain): 1 = the yaw stage of the vehicles done with XY runs beside the XY stage's continuation
+    launches (shorter latency of a batch that runs alone), 0 = stages strictly in turn; same results."""
     o = capi.SolverOpts()
     capi.load().tg_default_opts(C.byref(o))
     o.rho_scale[:] = [float(v) for v in rho_scale]
@@ -44,6 +46,7 @@ def make_opts(rho=0.0, sigma=1e-6, alpha=1.6, eps_abs=1e-3, eps_rel=1e-3, max_it
         o.phase_iters[p] = int(phase_iters[p])
         for k in range(4):
             o.phase_scale[p][k] = float(phase_scale[p][k])
+    o.overlap = int(overlap)
     return o
 
 
