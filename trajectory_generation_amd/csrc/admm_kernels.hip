@@ -1394,12 +1394,16 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     if (a.iters) a.iters[inst] = local;
                     if (a.res) { a.res[inst] = m_rp; a.res[(size_t)a.res_ld + inst] = m_rd; }
                 }
-                if (g == 0 && pexit) {
-                    a.next_list[atomicAdd(a.next_count, 1)] = inst;
-                    if (a.status) a.status[inst] = TG_DEV_UNSOLVED;   // not decided yet: a later launch of this solve will say
+                if (g == 0 && pexit) a.next_list[atomicAdd(a.next_count, 1)] = inst;
+                if constexpr (MIXED) {
+                    // the two-axis stage of the 12-state chain, whose next stage may start for the
+                    // vehicles that are done while the others continue: a handed-over vehicle's status
+                    // says "not decided yet" until a later launch of this solve decides, and launches
+                    // that are asked to list what they solve
+                    if (g == 0 && pexit && a.status) a.status[inst] = TG_DEV_UNSOLVED;
+                    if (g == 0 && fin && verdict == TG_DEV_SOLVED && a.done_list != nullptr)
+                        a.done_list[atomicAdd(a.done_count, 1)] = inst;
                 }
-                if (g == 0 && fin && verdict == TG_DEV_SOLVED && a.done_list != nullptr)
-                    a.done_list[atomicAdd(a.done_count, 1)] = inst;
                 if (a.warm_out || pexit) {
 #pragma unroll
                     for (int cc = 0; cc < MAXC; cc++) {
