@@ -22,6 +22,7 @@ run n20_6dof_fine5 --workload mpc_6dof_B4096_N20 --steps 200 --pipeline 1 --chec
 run n20_6dof_stress --workload mpc_6dof_B4096_N20 --steps 200 --pipeline 1 --stress --no-cpu-baseline --no-target-leg
 run n20_12state --workload mpc_12state_B4096_N20 --steps 200
 run n20_12state_serial --workload mpc_12state_B4096_N20 --steps 200 --pipeline 1 --no-cpu-baseline --no-target-leg
+run n20_12state_serial_overlap --workload mpc_12state_B4096_N20 --steps 200 --pipeline 1 --overlap --no-cpu-baseline --no-target-leg
 run n20_12state_smooth --workload mpc_12state_B4096_N20 --steps 200 --pipeline 1 --smoothing --no-cpu-baseline --no-target-leg
 run rollout_12state --workload rollout_12state_B8192_N20 --steps 500 --no-cpu-baseline --no-target-leg
 run rollout_6dof --workload rollout_6dof_B8192_N20 --steps 500 --no-cpu-baseline --no-target-leg
