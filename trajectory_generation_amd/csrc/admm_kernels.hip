@@ -983,12 +983,17 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
         // -------------------------------------------------------- relaxation, projection, dual
         if constexpr (CHK) { pin_n = 0.0; pin_l = 0.0; m_atdy = 0.0; }
         {
+            // The checking iteration of the variants with many cells per thread takes the cells one at a
+            // time: it carries the parts of A' delta_y beside everything else, and what a second cell's
+            // operands displace comes back from scratch memory, which at one check per 25 iterations is
+            // a cache miss every time.
+            constexpr int GP = (CHK && !MIXED && MAXC > 2) ? 1 : G;
 #pragma unroll
-            for (int c0 = 0; c0 < ((TG_ABLATE & 4) ? 0 : MAXC); c0 += G) {
-                double xt[G][S], xp[G][S], bnd[G][S][2], rr[CHK ? G : 1][S], bg[G][D];
-                double xn[CHK ? G : 1][D], pa[CHK ? G : 1][S], dnx[CHK ? G : 1][D], dm[(CHK && MIXED) ? 6 : 1];   // CHK: next cell's xt, A' delta_y parts
+            for (int c0 = 0; c0 < ((TG_ABLATE & 4) ? 0 : MAXC); c0 += GP) {
+                double xt[GP][S], xp[GP][S], bnd[GP][S][2], rr[CHK ? GP : 1][S], bg[GP][D];
+                double xn[CHK ? GP : 1][D], pa[CHK ? GP : 1][S], dnx[CHK ? GP : 1][D], dm[(CHK && MIXED) ? 6 : 1];   // CHK: next cell's xt, A' delta_y parts
 #pragma unroll
-                for (int j = 0; j < G; j++) {
+                for (int j = 0; j < GP; j++) {
                     const int cc = c0 + j;
                     if (cc >= MAXC) continue;
                     const double *xin = vx + i_var[cc];
@@ -1009,14 +1014,14 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                             xt[j][k] += xin[X2 + k * 16];
                             xp[j][k] += lds[i_prev2[cc] + k * 16];
                         }
-                        if constexpr (G > 1) {
+                        if constexpr (GP > 1) {
                             if (MIXED && (k == 1 || k == 2)) { bnd[j][k][1] = hiv[cc][k - 1]; bnd[j][k][0] = -bnd[j][k][1]; }
                             else if (REGC) { bnd[j][k][1] = c_hi[cc][k]; bnd[j][k][0] = k == 0 ? c_lo0[cc] : -c_hi[cc][k]; }
                             else { bnd[j][k][0] = clo(cc, k); bnd[j][k][1] = chi(cc, k); }
                             if constexpr (CHK) rr[j][k] = REGC ? c_rho[cc][k] : crho(cc, k);
                         }
                     }
-                    if constexpr (G > 1) {
+                    if constexpr (GP > 1) {
 #pragma unroll
                         for (int k = 0; k < D; k++) bg[j][k] = REGC ? c_bg[cc][k] : lds[i_bg[cc] + k * 16];
                     }
@@ -1035,7 +1040,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < G; j++) {
+                for (int j = 0; j < GP; j++) {
                     const int cc = c0 + j;
                     if (cc >= MAXC) continue;
                     const int cw = cell_of(cc);
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     for (int k = 0; k < S; k++) {
                         x[cc][k] = __builtin_fma(alpha, xt[j][k], oma * x[cc][k]);
                         double lo, hi;   // a single cell at a time reads its constants where they are used
-                        if constexpr (G > 1) { lo = bnd[j][k][0]; hi = bnd[j][k][1]; }
+                        if constexpr (GP > 1) { lo = bnd[j][k][0]; hi = bnd[j][k][1]; }
                         else if (MIXED && (k == 1 || k == 2)) { hi = hiv[cc][k - 1]; lo = -hi; }
                         else { lo = clo(cc, k); hi = chi(cc, k); }
                         double zo, yo;
@@ -1053,7 +1058,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                         const double s = zr + yo;
                         const double zn = clampd(s, lo, hi);
                         if constexpr (CHK) {
-                            double d = (G > 1 ? rr[j][k] : crho(cc, k)) * (zr - zn);
+                            double d = (GP > 1 ? rr[j][k] : crho(cc, k)) * (zr - zn);
                             if (hi > kInfBound) d = lo < -kInfBound ? 0.0 : fmin(d, 0.0);
                             else if (lo < -kInfBound) d = fmax(d, 0.0);
                             pin_n = fmax(pin_n, fabs(d));
@@ -1070,7 +1075,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
 #pragma unroll
                         for (int l = k; l < D; l++) zt = __builtin_fma(chain_coef<D>(k, l, dt, c2), xp[j][l], zt);
                         if (k == D - 1) zt = __builtin_fma(dt, xp[j][D], zt);
-                        const double b = G > 1 ? bg[j][k] : lds[i_bg[cc] + k * 16];
+                        const double b = GP > 1 ? bg[j][k] : lds[i_bg[cc] + k * 16];
                         const double zr = __builtin_fma(alpha, zt, oma * b);
                         const double s = zr + yg[cc][k];
                         yg[cc][k] = s - b;
@@ -1133,7 +1138,7 @@ __global__ __launch_bounds__(NT) void admm_kernel(const StageDev P, const BatchA
                     // ||A' delta_y||_inf over the cells' variables: own rows + the next step's dynamics
                     // rows + the step's mixed rows
 #pragma unroll
-                    for (int j = 0; j < G; j++) {
+                    for (int j = 0; j < GP; j++) {
                         const int cc = c0 + j;
                         if (cc >= MAXC) continue;
                         double mixc[3] = {0.0, 0.0, 0.0};
