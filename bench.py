@@ -112,6 +112,7 @@ def cpu_baseline(model, N, seed_off, eps, rho, eng, check=25, check_fine=0, smoo
     from oracle import oracle as O
     from trajectory_generation_amd.synth import stress as synth_stress
     O.build()
+    native = O.use_native()        # built here, for this machine's cores (the portable build is the fallback)
     threads = _host_threads()
     sample, single = (2048, 256) if model == "6dof" else (512, 128)   # all-cores leg, one-core leg
     if model == "6dof":
@@ -159,7 +160,7 @@ def cpu_baseline(model, N, seed_off, eps, rho, eng, check=25, check_fine=0, smoo
                       "every 50 iterations and kept from one instance to the next as by a solver object in use, eps as "
                       "the GPU run) and a sparse LDL' of the KKT matrix (minimum-degree ordering); upstream OSQP "
                       "25b6b39 is not available offline" % (sample, threads),
-            "cpu_model": _cpu_model(),
+            "cpu_model": _cpu_model(), "build": native or "-O3 (portable build: the native one failed)",
             "iters_mean": float(np.mean(rall["iters"])), "solved_frac": solved(rall),
             "single_core": {"value": single / dt1, "instances": single, "iters_mean": float(np.mean(r1["iters"])),
                             "solved_frac": solved(r1)},

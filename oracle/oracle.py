@@ -28,6 +28,25 @@ def build(force=False):
     return _LIB_PATH
 
 
+def use_native():
+    """For timing the CPU baseline on the machine it runs on: the same sources built with
+    -march=native into oracle/_native/ (the portable liboracle.so has to run on whatever machine the
+    tree travels to), loaded in place of it.  Call before anything else of this module is used.
+    Returns the flags used, or None when the build failed and the portable library stays."""
+    global _LIB_PATH, _lib
+    flags = ["-O3", "-march=native", "-fPIC", "-std=gnu11", "-fno-fast-math", "-ffp-contract=off"]
+    out_dir = os.path.join(_HERE, "_native")
+    out = os.path.join(out_dir, "liboracle_native.so")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call([os.environ.get("CC", "gcc")] + flags + ["-shared", "-o", out, os.path.join(_HERE, "osqp_restate.c"),
+                               os.path.join(_HERE, "mpc_qp.c"), "-lm"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    _LIB_PATH, _lib = out, None
+    return " ".join(flags)
+
+
 class Settings(C.Structure):
     _fields_ = [("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
                 ("eps_abs", C.c_double), ("eps_rel", C.c_double),
