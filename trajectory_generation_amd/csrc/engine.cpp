@@ -1097,6 +1097,11 @@ static int mpc12_chain(tg_mpc12 *h, const InterView &iv, int B, int ld, const do
     // on a second stream beside the continuation launches, and the vehicles those solve get their
     // yaw stage afterwards, from the list the continuation launches write.  Every vehicle's three
     // solves are what they are in the sequential chain, bit for bit.
+    // (The early pass forms the yaw reference of every vehicle, also of those whose XY rows the
+    // continuation launches are still writing: such a vehicle is gated out of that pass by the copy of
+    // the XY statuses taken before, and its reference is formed again for the late pass, after the
+    // continuation launches and after the early pass has ended.  The two passes never run at once,
+    // so the yaw stage's own buffers -- warm rows, hand-over lists, queue counter -- see one at a time.)
     if ((rc = h->ensure_overlap(ld))) return rc;
     int *gate = h->d_ovl, *late = gate + h->ovl_cap, *late_n = late + h->ovl_cap;
     const int yaw_warm_in = warm ? (h->st[TG_FAM_YAW].warm_rows_valid(B) ? 1 : 0) : -1;
