@@ -54,6 +54,7 @@ def draw_opts(N):
         k2 = k1 + int(rng_sched.integers(1, 8)) * int(rng_sched.choice([5, 10, 25, 40])) if kind == 3 else -1
         e["phase_iters"] = (k1, k2)
         e["phase_scale"] = tuple(tuple(float(v) for v in 10 ** rng_sched.uniform(-0.5, 1.5, 4)) for _ in range(2))
+    e["overlap"] = int(rng_sched.integers(0, 2))      # 12-state chain: yaw stage of the early XY finishers beside the XY continuation launches
     import json
     e.update(json.loads(os.environ.get("FUZZ_ENGINE_ONLY", "{}")))      # overrides for bisecting a finding
     for k, v in json.loads(os.environ.get("FUZZ_BOTH", "{}")).items():
@@ -265,7 +266,7 @@ for trial in range(TRIALS):
                     max_vel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2, 3)),
                     max_accel=tuple(float(v) for v in 10 ** rng.uniform(-0.5, 2, 3)),
                     max_jerk=tuple(float(v) for v in 10 ** rng.uniform(0, 3, 3)))
-    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap", "phase_iters") if k in e})
+    desc = "N %2d B %2d dt %.2f sm %d %s" % (N, B, dt, smooth, {k: e[k] for k in ("eps_abs", "alpha", "max_iter", "check_termination", "check_fine", "lowrank", "grid_cap", "phase_iters", "overlap") if k in e})
     try:
         if ONLY and trial not in ONLY:
             raise KeyError("skipped")
