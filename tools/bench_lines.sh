@@ -1,4 +1,4 @@
-# The bench lines quoted in DESIGN.md (run on the GPU box from the repository root).
+# The bench lines of a round, one JSON file each (run on the GPU box from the repository root).
 ROUND=${ROUND:-r03}; O=gpurun_out/bench_$ROUND; mkdir -p $O
 run() { n=$1; shift; timeout -k 10 400 python bench.py "$@" > $O/$n.json 2> $O/$n.err || { echo "FAILED $n"; exit 1; }; python - $O/$n.json $n <<'P'
 import json, sys
