@@ -42,7 +42,7 @@ WORKLOADS = {
 DEFAULT_WORKLOAD = "mpc_6dof_B262144_N50"
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (v_mfma_f64_16x16x4: 2048 flop / 64 clk / SIMD at 2.4 GHz)
 FP64_MFMA_SUSTAINED_TFLOPS = 75.7   # tools/microbench/mfma_valu_overlap.hip on the box: register-only MFMA, two chains per SIMD
-PIPELINE = {"mpc_12state_B4096_N20": 6, "mpc_6dof_B4096_N20": 4, "mpc_6dof_B32768_N50": 3,
+PIPELINE = {"mpc_12state_B4096_N20": 6, "mpc_6dof_B4096_N20": 4, "mpc_6dof_B32768_N50": 4,
             "rollout_12state_B8192_N20": 4}   # closed loop: sub-fleets, each on its own stream   # default batches in flight (--pipeline 0)
 MIN_TIMED_S = 2.0              # shorter regions are repeated until this much has been timed
 PROFILE_ROUND = "r03"
@@ -285,7 +285,8 @@ def main():
     # whole batch keeps one in flight: there the tail is a few per cent.
     ranks_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.pipeline <= 0 and args.workload in WORKLOADS and WORKLOADS[args.workload][4] == "total" and ranks_env > 1:
-        depth = 3 if WORKLOADS[args.workload][1] // ranks_env <= 65536 else 2
+        share = WORKLOADS[args.workload][1] // ranks_env
+        depth = 4 if share <= 32768 else 3 if share <= 65536 else 2      # 32768 at N = 50: 17.9 M solves/s with four, 17.5 M with three
     if depth > 1:
         os.environ["GPU_MAX_HW_QUEUES"] = "8"
 
